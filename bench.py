@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Throughput of the per-pixel Monte-Carlo loop on MI355X.
+
+One step = one complete render of the benchmark workload (Cornell box,
+1024x1024, depth 6, 1000 samples per pixel, IS+ES+RR) with the scene resident
+on the GPU.  With N GPUs the image rows are dealt out in bands, every rank
+renders its rows, and the accumulators are gathered on rank 0 (RCCL) inside
+the timed region.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# Algorithmic work per path for this workload: 80 (primary ray) + 6.82 rays x 489 FLOP (seven spheres, one plane,
+# hit attributes) + 4.08 bounces x 120 FLOP (shading) + 10 (accumulate).
+FLOP_PER_PATH = 3.9e3
+PEAK_FP32_TFLOPS = 157.3
+
+
+def cpu_baseline(sx, depth, flags, seconds_target=15.0):
+    """Times the CPU side on a bounded sample of the same workload: the compiled reference if it was built
+    (oracle/_ref), else the CPU oracle."""
+    import ctypes as C
+
+    import numpy as np
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    ref_lib = os.path.join(REPO, "oracle", "_ref", f"libptref_f{flags}.so")
+    small = 256
+    dp = C.POINTER(C.c_double)
+    if os.path.exists(ref_lib):
+        lib = C.CDLL(ref_lib)
+        lib.ref_select_scene.argtypes = [C.c_char_p, C.c_int]
+        lib.ref_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, C.c_int]
+        lib.ref_rng_counter.argtypes = [C.c_uint64]
+        lib.ref_select_scene(b"cornell", depth)
+        lib.ref_rng_counter(1)
+        rgb, w = np.zeros(small * small * 3), np.ones(small * small)
+
+        def run(k0, nk):
+            lib.ref_render(small, k0, nk, 0.0, rgb.ctypes.data_as(dp), w.ctypes.data_as(dp), threads)
+
+        kind = "reference"
+    else:
+        import pathtracer_amd as pt
+        from harness import Oracle
+
+        orc = Oracle(pt.Scene.from_file(os.path.join(REPO, "tests", "golden", "cornell.ptxscene")))
+        prm = pt.make_params(small, depth, flags, 0.0, seed=1)
+        rgb, w = np.zeros(small * small * 3), np.ones(small * small)
+
+        def run(k0, nk):
+            orc.render(prm, k0, nk, rgb, w, threads)
+
+        kind = "port"
+    t0 = time.perf_counter()
+    run(0, 4)
+    t4 = time.perf_counter() - t0
+    spp = max(4, min(2000, int(seconds_target / max(t4 / 4, 1e-6))))
+    t0 = time.perf_counter()
+    run(4, spp)
+    dt = time.perf_counter() - t0
+    return {
+        "value": small * small * spp / dt,
+        "unit": "paths/s",
+        "cores": threads,
+        "kind": kind,
+        "sample": f"Cornell {small}x{small}, depth {depth}, {spp} spp, flags IS+ES+RR, {dt:.1f} s of CPU work, "
+                  f"rows shared by {threads} OpenMP threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--chunk", type=int, default=0, help="passes per kernel launch (0 = all of them in one launch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import pathtracer_amd as pt
+    from pathtracer_amd import parallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be started through torch.distributed.run with N ranks")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    flags = pt.abi.USE_IS | pt.abi.USE_ES | pt.abi.USE_RR
+    sx, spp, depth = args.size, args.spp, args.depth
+    chunk = args.chunk if args.chunk > 0 else spp
+    band = parallel.band_rows_for(sx, world)
+    scene = pt.Scene.from_file(os.path.join(REPO, "tests", "golden", "cornell.ptxscene"))
+    dev = pt.Device(local_rank)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev.scene_upload(scene)
+    prm = pt.make_params(sx, depth, flags, 0.0, seed=2024, rank=rank, n_ranks=world, band_rows=band)
+    rows = parallel.local_row_count(sx, rank, world, band)
+    rgb = torch.zeros(rows * sx * 3, dtype=torch.float64, device=device)
+    wght = torch.ones(rows * sx, dtype=torch.float64, device=device)
+    kernel_ms = []
+
+    def step(record):
+        rgb.zero_()
+        wght.fill_(1.0)
+        dev.render_begin(prm, rgb.data_ptr(), wght.data_ptr())
+        k = 0
+        while k < spp:
+            nk = min(chunk, spp - k)
+            dev.render_passes(k, nk)
+            if record:
+                kernel_ms.append((dev.last_pass_ms(), nk))
+            k += nk
+        return parallel.gather_accumulators(rgb, wght, sx, rank, world, band)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, _w = step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    stats = dev.stats()
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    total_paths = sx * sx * spp * args.steps
+    paths_per_s = total_paths / dt
+    # dominant kernel: k_render; per launch it processes rows*sx*nk paths
+    ms_sum = sum(m for m, _ in kernel_ms)
+    paths_launches = sum(rows * sx * nk for _, nk in kernel_ms)
+    achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
+    rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
+    out = {
+        "metric": "paths/s (pixel-samples per second), Cornell box 1024^2 depth 6 IS+ES+RR",
+        "value": paths_per_s,
+        "unit": "paths/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"CornellBox {sx}x{sx}, depth {depth}, {spp} spp, IS=1 ES=1 RR=1, aperture 0",
+            "passes_per_launch": chunk,
+            "band_rows": band,
+            "parallelism": f"rows in bands over {world} GPU(s), gather to rank 0",
+        },
+        "mrays_per_s": paths_per_s * rays_per_path / 1e6,
+        "rays_per_path": rays_per_path,
+        "roofline": {
+            "bound": "valu",
+            "achieved": achieved_tflops,
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+            "traffic": None,
+            "kernel": "k_render",
+            "kernel_ms_avg": ms_sum / max(1, len(kernel_ms)),
+            "flop_per_path_model": FLOP_PER_PATH,
+            "note": "vector FP32 peak (no MFMA: the work is not a dense contraction); arithmetic runs in FP64 "
+                    "(peak 78.6 TFLOP/s), so frac against the FP64 vector peak is twice this value",
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sx, depth, flags)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

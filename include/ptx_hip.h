@@ -1,0 +1,135 @@
+/*
+ * ptx_hip.h -- C ABI of libptx_hip.so, the MI355X (gfx950) implementation of
+ * PathTracer's per-pixel Monte-Carlo loop.
+ *
+ * The reference has no plugin or FFI layer.  Its hot path is reached through
+ * C globals (object_list, light_list, boxtree, texture_list, cam, MAX_DEPTH:
+ * PathTracer.c:34-40) and the body of the sample loop in main()
+ * (PathTracer.c:617-654).  The functions below are what a host program calls
+ * in place of that loop body; each comment names the reference code it
+ * stands in for.  Everything is plain C: pointers, sizes, ints.  All
+ * functions return 0 on success and a negative PTX_E* code on failure;
+ * ptx_last_error() then describes the failure.  (The reference itself only
+ * prints to stderr and calls exit(0): PathTracer.c:511-520, :552-555,
+ * :570-581.)
+ *
+ * Threading: a context is used from one host thread at a time, as the
+ * reference's main() is.  One context drives one GPU; a multi-GPU job is
+ * one process (and one context) per GPU, each given its share of the image
+ * rows through ptx_render_params.rank / n_ranks / band_rows.
+ */
+#ifndef PTX_HIP_H
+#define PTX_HIP_H
+
+#include "ptx_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PTX_OK = 0,
+    PTX_EINVAL = -1,   /* bad argument or scene */
+    PTX_EDEVICE = -2,  /* HIP runtime error */
+    PTX_ESTATE = -3,   /* call made in the wrong order */
+    PTX_ENOMEM = -4
+};
+
+typedef struct ptx_context ptx_context;
+
+/* Exact work counters since ptx_render_begin.  Stands in for NUM_RAYS
+ * (PathTracer.c:39, :645), which counts paths only and loses updates under
+ * OpenMP. */
+typedef struct ptx_stats {
+    uint64_t paths;         /* pixel-samples traced */
+    uint64_t closest_hits;  /* closest-hit queries (PathTracer.c:282) */
+    uint64_t shadow_rays;   /* explicit-light queries (PathTracer.c:428) */
+    uint64_t rindex_oob;    /* refraction-stack accesses outside [0,9] */
+} ptx_stats;
+
+/* Creates a context on HIP device `device`.  No counterpart in the
+ * reference (it has no device). */
+int ptx_init(int device, ptx_context **ctx);
+
+/* Releases every device buffer and the context. */
+void ptx_shutdown(ptx_context *ctx);
+
+/* Copies the scene to the GPU and builds the acceleration structure.  Call
+ * after buildScene(), build_boxtree() and the light-weight normalisation
+ * (PathTracer.c:563-566, :600-611) have produced the flat description; it
+ * replaces the hot path's reads of object_list / light_list / boxtree /
+ * texture_list / cam.  The description may be freed afterwards. */
+int ptx_scene_upload(ptx_context *ctx, const ptx_scene_desc *scene);
+
+/* Starts a render: allocates the radiance accumulator (all zero) and the
+ * per-pixel weights (all one) for this rank's rows, as newImage() and the
+ * wght loop do (PathTracer.c:550-557), and zeroes the counters.  Only
+ * PTX_RNG_COUNTER is implemented on the GPU. */
+int ptx_render_begin(ptx_context *ctx, const ptx_render_params *params);
+
+/* As ptx_render_begin, but the accumulators live in device memory the
+ * caller owns (for example torch tensors that a collective will read):
+ * d_rgb holds rows_owned*sx*3 doubles, d_wght rows_owned*sx doubles, local
+ * row order.  The caller initialises them (0 and 1 for a new render). */
+int ptx_render_begin_external(ptx_context *ctx, const ptx_render_params *params, double *d_rgb, double *d_wght);
+
+/* Runs passes k0 .. k0+nk-1 of the sample loop for every pixel this rank
+ * owns: primary ray, PathTrace, and the ordered fold into the accumulator
+ * (PathTracer.c:617-654 without the dataOutput call at :655).  Returns
+ * once the work is queued on the context's stream. */
+int ptx_render_passes(ptx_context *ctx, int k0, int nk);
+
+/* Waits for queued work (the reference's loop is synchronous). */
+int ptx_sync(ptx_context *ctx);
+
+/* Copies this rank's rows of the accumulators into whole-image host
+ * buffers laid out like the reference's rgbIm (sx*sx*3 doubles) and wght
+ * (sx*sx doubles) (PathTracer.c:550-557); rows of other ranks are left
+ * untouched.  Either pointer may be NULL.  What the host calls before
+ * dataOutput() (PathTracer.c:655, :661). */
+int ptx_download(ptx_context *ctx, double *rgbIm, double *wght);
+
+/* Device addresses of this rank's accumulators and the number of rows they
+ * hold (for a device-side gather).  */
+int ptx_accumulators(ptx_context *ctx, double **d_rgb, double **d_wght, int32_t *rows_owned);
+
+/* findFirstHit (PathTracer.c:198-251) for n rays in host memory; the ray
+ * direction is used as given, as in the reference.  hits[i].obj is the
+ * index into the uploaded objects[] or -1.  For triangles and rooms a and b
+ * are returned as 0 (the reference leaves them unset). */
+int ptx_first_hit(ptx_context *ctx, const ptx_ray *rays, int64_t n, ptx_hit *hits);
+
+/* The same for rays and hits already in device memory. */
+int ptx_first_hit_device(ptx_context *ctx, const ptx_ray *d_rays, int64_t n, ptx_hit *d_hits);
+
+/* Radiance of n individual paths (pixel i,j of an sx-wide image, sample
+ * index k): the value PathTrace returns in *col (PathTracer.c:644) before
+ * it is folded into the image.  out holds 3*n doubles, host memory.  Uses
+ * the flags, depth, aperture and seed of params. */
+int ptx_trace_paths(ptx_context *ctx, const ptx_render_params *params, const int32_t *pix_i, const int32_t *pix_j,
+                    const int32_t *sample, int64_t n, double *out);
+
+/* Counters accumulated since ptx_render_begin (synchronises). */
+int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);
+
+/* Device time in milliseconds of the most recent ptx_render_passes launch,
+ * from HIP events recorded on the context's stream around the kernel
+ * (synchronises).  The reference times with time(NULL) at 1 s resolution
+ * (PathTracer.c:614, :658). */
+int ptx_last_pass_ms(ptx_context *ctx, float *ms);
+
+/* Makes the context launch on an existing hipStream_t (passed as void*),
+ * e.g. the stream a caller's framework is using.  NULL restores the
+ * context's own stream. */
+int ptx_set_stream(ptx_context *ctx, void *hip_stream);
+
+/* Text of the last error on the calling thread. */
+const char *ptx_last_error(void);
+
+/* Library version, "major.minor". */
+const char *ptx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -117,8 +117,39 @@ typedef struct ptx_render_params {
     int32_t rng_mode;    /* PTX_RNG_* */
     double aperture;     /* PathTracer.c:525-529 */
     uint64_t seed;
-    int32_t row0, n_rows; /* rows [row0,row0+n_rows) of the image handled here */
+    /* Which image rows this call works on.  Rows are grouped in bands of
+     * band_rows consecutive rows; band b belongs to rank (b % n_ranks).
+     * n_ranks = 1 (or 0) means the whole image.  The reference has one
+     * process and no such split (PathTracer.c:620 shares rows among OpenMP
+     * threads instead). */
+    int32_t rank, n_ranks, band_rows, pad;
 } ptx_render_params;
+
+#if defined(__HIPCC__)
+#define PTX_SCENE_FN __host__ __device__ static inline
+#else
+#define PTX_SCENE_FN static inline
+#endif
+
+/* Number of rows owned by (rank, n_ranks, band_rows) in an sx-row image, and
+ * the local index of an owned row j (or -1 if j is not owned). */
+PTX_SCENE_FN int32_t ptx_rows_owned(int32_t sx, int32_t rank, int32_t n_ranks, int32_t band_rows) {
+    if (n_ranks <= 1) return sx;
+    int32_t n = 0;
+    for (int32_t j0 = 0; j0 < sx; j0 += band_rows)
+        if ((j0 / band_rows) % n_ranks == rank) n += (sx - j0 < band_rows ? sx - j0 : band_rows);
+    return n;
+}
+PTX_SCENE_FN int32_t ptx_local_row(int32_t j, int32_t rank, int32_t n_ranks, int32_t band_rows) {
+    if (n_ranks <= 1) return j;
+    int32_t b = j / band_rows;
+    if (b % n_ranks != rank) return -1;
+    return (b / n_ranks) * band_rows + j % band_rows;
+}
+PTX_SCENE_FN int32_t ptx_global_row(int32_t local, int32_t rank, int32_t n_ranks, int32_t band_rows) {
+    if (n_ranks <= 1) return local;
+    return ((local / band_rows) * n_ranks + rank) * band_rows + local % band_rows;
+}
 
 /* One ray for the first-hit entry points.  os is the index of the object
  * to skip (the reference's Os pointer) or -1. */

@@ -959,8 +959,7 @@ void orc_render(const orc_scene *s, const ptx_render_params *prm, int k0, int nk
     matvec(cam->C2W, &fp);
     int par = prm->rng_mode == PTX_RNG_COUNTER && threads != 1;
     if (threads <= 0) threads = omp_get_max_threads();
-    int row0 = prm->row0, row1 = prm->row0 + prm->n_rows;
-    if (prm->n_rows <= 0) { row0 = 0; row1 = sx; }
+    int n_local = ptx_rows_owned(sx, prm->rank, prm->n_ranks, prm->band_rows);
     orc_stats total;
     memset(&total, 0, sizeof(total));
     for (int k = k0; k < k0 + nk; k++) {
@@ -969,7 +968,8 @@ void orc_render(const orc_scene *s, const ptx_render_params *prm, int k0, int nk
             orc_stats st;
             memset(&st, 0, sizeof(st));
 #pragma omp for schedule(dynamic, 1)
-            for (int j = row0; j < row1; j++) {
+            for (int jl = 0; jl < n_local; jl++) {
+                int j = ptx_global_row(jl, prm->rank, prm->n_ranks, prm->band_rows);
                 for (int i = 0; i < sx; i++) {
                     rng_t rng;
                     rng.mode = prm->rng_mode == PTX_RNG_COUNTER ? 0 : 1;

@@ -37,8 +37,8 @@ const ptx_scene_desc *orc_scene_desc(const orc_scene *s);
 /* findFirstHit for n rays (directions used as given, not normalised). */
 void orc_first_hit(const orc_scene *s, const ptx_ray *rays, int n, ptx_hit *hits);
 
-/* Passes k0 .. k0+nk-1 of the sample loop over rows [row0,row0+n_rows) of
- * the sx*sx image.  rgb (sx*sx*3) and wght (sx*sx) are whole-image buffers
+/* Passes k0 .. k0+nk-1 of the sample loop over the rows of the sx*sx image
+ * that prm assigns to its rank (all rows when n_ranks <= 1).  rgb (sx*sx*3) and wght (sx*sx) are whole-image buffers
  * that are read and updated.  threads<=0: all cores (counter stream only;
  * the LCG48 stream always runs serially).  lcg_state is the running
  * drand48 state for PTX_RNG_LCG48 (in/out), ignored otherwise. */

@@ -1,0 +1,571 @@
+// ptx_hip.hip -- kernels and C ABI of libptx_hip.so (gfx950 / MI355X).
+//
+// Execution model.  One lane owns one pixel for the whole launch and walks
+// through that pixel's samples in order: when its path ends it folds the
+// colour into the pixel's accumulator (held in registers), advances to the
+// next sample and starts a new primary ray in the same loop iteration, so a
+// wave stays busy until its slowest pixel has finished all samples.  This
+// keeps the reference's per-pixel, order-dependent accumulation
+// (PathTracer.c:643-652) exact without any inter-lane traffic, needs no
+// queues in HBM, and touches memory only to read the scene (scalar loads of
+// a few KB that stay in the scalar cache) and to load/store 32 bytes of
+// accumulator per pixel per launch.  A wave covers an 8x8 pixel tile so that
+// its lanes follow similar paths.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ptx_device.h"
+#include "ptx_hip.h"
+
+// ------------------------------------------------------------------ kernels
+template <int FLAGS>
+__global__ void __launch_bounds__(256) k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb,
+                                                 double *__restrict__ wght, unsigned long long *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tiles_x = (rp.sx + 7) >> 3;
+    const int tx = wave % tiles_x, ty = wave / tiles_x;
+    const int i = tx * 8 + (lane & 7);
+    const int jl = ty * 8 + (lane >> 3);
+    const bool inside = i < rp.sx && jl < rp.rows_owned;
+    const int j = inside ? ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows) : 0;
+    const size_t pix = inside ? (size_t)jl * rp.sx + i : 0;
+
+    double acc_r = 0, acc_g = 0, acc_b = 0, wt = 1;
+    if (inside) {
+        acc_r = rgb[pix * 3 + 0];
+        acc_g = rgb[pix * 3 + 1];
+        acc_b = rgb[pix * 3 + 2];
+        wt = wght[pix];
+    }
+    Counters cnt = {0, 0, 0};
+    uint32_t paths = 0;
+    Path ps;
+    bool alive = false;
+    int k = inside ? k0 : k1;
+    const bool track = sc.has_refraction != 0;
+    for (;;) {
+        if (!alive && k < k1) {
+            primary_ray(sc, rp, i, j, k, track, ps);
+            alive = true;
+        }
+        if (__ballot(alive) == 0ULL) break;
+        if (alive) {
+            if (bounce<FLAGS>(sc, rp, ps, cnt)) {
+                // fold, reference PathTracer.c:646-652
+                double f = exp2(-log(wt));
+                acc_r += ps.I.x * f;
+                acc_g += ps.I.y * f;
+                acc_b += ps.I.z * f;
+                wt += ps.I.x;
+                wt += ps.I.y;
+                wt += ps.I.z;
+                alive = false;
+                k++;
+                paths++;
+            }
+        }
+    }
+    if (inside) {
+        rgb[pix * 3 + 0] = acc_r;
+        rgb[pix * 3 + 1] = acc_g;
+        rgb[pix * 3 + 2] = acc_b;
+        wght[pix] = wt;
+    }
+    // one set of atomics per wave
+    unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off);
+        c1 += __shfl_down(c1, off);
+        c2 += __shfl_down(c2, off);
+        c3 += __shfl_down(c3, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&stats[0], c0);
+        atomicAdd(&stats[1], c1);
+        atomicAdd(&stats[2], c2);
+        if (c3) atomicAdd(&stats[3], c3);
+    }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
+                                                      const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
+                                                      long n, double *__restrict__ out) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    Counters cnt = {0, 0, 0};
+    Path ps;
+    primary_ray(sc, rp, pi[q], pj[q], pk[q], sc.has_refraction != 0, ps);
+    while (!bounce<FLAGS>(sc, rp, ps, cnt)) {
+    }
+    out[3 * q + 0] = ps.I.x;
+    out[3 * q + 1] = ps.I.y;
+    out[3 * q + 2] = ps.I.z;
+}
+
+__global__ void __launch_bounds__(256) k_first_hit(DevScene sc, const ptx_ray *__restrict__ rays, long n,
+                                                    ptx_hit *__restrict__ hits) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    ptx_ray r = rays[q];
+    V3 p0 = mk(r.p0[0], r.p0[1], r.p0[2]), d = mk(r.d[0], r.d[1], r.d[2]);
+    Hit h = closest_hit_all(sc, p0, d, r.os);
+    ptx_hit o;
+    o.lambda = -1;
+    o.obj = -1;
+    o.pad = 0;
+    o.p[0] = o.p[1] = o.p[2] = 0;
+    o.n[0] = o.n[1] = o.n[2] = 0;
+    o.a = o.b = 0;
+    if (h.obj >= 0) {
+        V3 p, nn;
+        double a, b;
+        finish_hit<true>(sc, h, p0, d, p, nn, a, b);
+        o.lambda = h.lambda;
+        o.obj = h.obj;
+        o.p[0] = p.x; o.p[1] = p.y; o.p[2] = p.z;
+        o.n[0] = nn.x; o.n[1] = nn.y; o.n[2] = nn.z;
+        o.a = a; o.b = b;
+    }
+    hits[q] = o;
+}
+
+__global__ void k_fill(double *p, size_t n, double v) {
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) p[q] = v;
+}
+
+// ---------------------------------------------------------------- host side
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(PTX_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct ptx_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+    // scene
+    bool have_scene = false;
+    DevScene sc{};
+    void *d_geom = nullptr, *d_mat = nullptr, *d_lights = nullptr, *d_images = nullptr, *d_texels = nullptr;
+    int n_objects = 0;
+    // render
+    bool rendering = false;
+    ptx_render_params prm{};
+    DevRender rp{};
+    double *d_rgb = nullptr, *d_wght = nullptr;
+    bool own_accum = false;
+    unsigned long long *d_stats = nullptr;
+};
+
+static void free_scene(ptx_context *c) {
+    for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels}) (void)hipFree(q);
+    c->d_geom = c->d_mat = c->d_lights = c->d_images = c->d_texels = nullptr;
+    c->have_scene = false;
+}
+static void free_render(ptx_context *c) {
+    if (c->own_accum) { (void)hipFree(c->d_rgb); (void)hipFree(c->d_wght); }
+    c->d_rgb = c->d_wght = nullptr;
+    c->own_accum = false;
+    c->rendering = false;
+}
+
+extern "C" const char *ptx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ptx_version(void) { return "0.1"; }
+
+extern "C" int ptx_init(int device, ptx_context **out) {
+    if (!out) return fail(PTX_EINVAL, "ptx_init: null output pointer");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PTX_EINVAL, "ptx_init: no such device");
+    HIPCHK(hipSetDevice(device));
+    ptx_context *c = new ptx_context();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+    *out = c;
+    return PTX_OK;
+}
+
+extern "C" void ptx_shutdown(ptx_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_render(c);
+    free_scene(c);
+    (void)hipFree(c->d_stats);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int ptx_set_stream(ptx_context *c, void *s) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PTX_OK;
+}
+
+// 3x4 affine part of a row-major 4x4 matrix
+static void affine34(const double *m4, double *m) {
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 4; q++) m[4 * r + q] = m4[4 * r + q];
+}
+// normalize(cross(v2-v1, v3-v1)) in the reference's operation order
+// (triangleIntersect, utils_path.c:788-795), on the host so that the stored
+// normal has the bits the reference recomputes at every test
+static void tri_normal(const ptx_object &o, double *n) {
+    double e12[3], e13[3];
+    for (int q = 0; q < 3; q++) {
+        e12[q] = o.v[1][q] + o.v[0][q] * -1;
+        e13[q] = o.v[2][q] + o.v[0][q] * -1;
+    }
+    double x = (e12[1] * e13[2]) - (e13[1] * e12[2]);
+    double y = (e13[0] * e12[2]) - (e12[0] * e13[2]);
+    double z = (e12[0] * e13[1]) - (e13[0] * e12[1]);
+    double l = x * x;
+    l += (y * y);
+    l += (z * z);
+    l = 1.0 / sqrt(l);
+    n[0] = x * l;
+    n[1] = y * l;
+    n[2] = z * l;
+}
+
+extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
+    if (!c || !s) return fail(PTX_EINVAL, "ptx_scene_upload: null argument");
+    if (s->magic != PTX_SCENE_MAGIC) return fail(PTX_EINVAL, "ptx_scene_upload: bad magic");
+    if (s->n_objects <= 0 || !s->objects) return fail(PTX_EINVAL, "ptx_scene_upload: scene has no objects");
+    if (s->n_lights < 0 || s->n_images < 0) return fail(PTX_EINVAL, "ptx_scene_upload: negative count");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_scene(c);
+    const int n = s->n_objects;
+    std::vector<DevGeom> geom(n);
+    std::vector<DevMat> mat(n);
+    int has_refr = 0;
+    for (int k = 0; k < n; k++) {
+        const ptx_object &o = s->objects[k];
+        if (o.type < PTX_PLANE || o.type > PTX_ROOM) return fail(PTX_EINVAL, "ptx_scene_upload: unknown object type");
+        for (int32_t img : {o.tex_img, o.normal_img, o.alpha_img})
+            if (img >= s->n_images) return fail(PTX_EINVAL, "ptx_scene_upload: image index out of range");
+        DevGeom &g = geom[k];
+        memset(&g, 0, sizeof(g));
+        g.type = o.type;
+        if (o.type == PTX_TRIANGLE) {
+            for (int v = 0; v < 3; v++)
+                for (int q = 0; q < 3; q++) g.m[3 * v + q] = o.v[v][q];
+            tri_normal(o, &g.m[9]);
+        } else {
+            affine34(o.Tinv, g.m);
+        }
+        DevMat &m = mat[k];
+        memset(&m, 0, sizeof(m));
+        for (int q = 0; q < 3; q++) m.col[q] = o.col[q];
+        m.diffPct = o.diffPct; m.reflPct = o.reflPct; m.tranPct = o.tranPct;
+        m.refl_sig = o.refl_sig; m.r_index = o.r_index; m.surfaceArea = o.surfaceArea;
+        m.is_light = o.is_light; m.tex_img = o.tex_img; m.normal_img = o.normal_img; m.alpha_img = o.alpha_img;
+        if (o.tranPct > 0 || o.alpha_img >= 0) has_refr = 1;
+    }
+    std::vector<DevLight> lights(s->n_lights > 0 ? s->n_lights : 1);
+    memset(lights.data(), 0, lights.size() * sizeof(DevLight));
+    for (int l = 0; l < s->n_lights; l++) {
+        int oi = s->lights[l];
+        if (oi < 0 || oi >= n) return fail(PTX_EINVAL, "ptx_scene_upload: light index out of range");
+        const ptx_object &o = s->objects[oi];
+        lights[l].obj = oi;
+        lights[l].type = o.type;
+        lights[l].weight = o.LSweight;
+        affine34(o.T, lights[l].T);
+    }
+    std::vector<DevImage> images(s->n_images > 0 ? s->n_images : 1);
+    memset(images.data(), 0, images.size() * sizeof(DevImage));
+    for (int q = 0; q < s->n_images; q++) {
+        const ptx_image &im = s->images[q];
+        uint64_t bytes = (uint64_t)im.sx * im.sy * im.channels;
+        if (im.sx <= 0 || im.sy <= 0 || (im.channels != 1 && im.channels != 3) || im.data_offset + bytes > s->n_texel_bytes)
+            return fail(PTX_EINVAL, "ptx_scene_upload: bad image descriptor");
+        images[q].sx = im.sx; images[q].sy = im.sy; images[q].channels = im.channels;
+        images[q].divisor = im.divisor; images[q].offset = im.data_offset;
+    }
+    HIPCHK(hipMalloc(&c->d_geom, geom.size() * sizeof(DevGeom)));
+    HIPCHK(hipMalloc(&c->d_mat, mat.size() * sizeof(DevMat)));
+    HIPCHK(hipMalloc(&c->d_lights, lights.size() * sizeof(DevLight)));
+    HIPCHK(hipMalloc(&c->d_images, images.size() * sizeof(DevImage)));
+    HIPCHK(hipMalloc(&c->d_texels, s->n_texel_bytes ? s->n_texel_bytes : 16));
+    HIPCHK(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_mat, mat.data(), mat.size() * sizeof(DevMat), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_images, images.data(), images.size() * sizeof(DevImage), hipMemcpyHostToDevice));
+    if (s->n_texel_bytes) HIPCHK(hipMemcpy(c->d_texels, s->texels, s->n_texel_bytes, hipMemcpyHostToDevice));
+    DevScene &d = c->sc;
+    memset(&d, 0, sizeof(d));
+    d.geom = (const DevGeom *)c->d_geom;
+    d.mat = (const DevMat *)c->d_mat;
+    d.lights = (const DevLight *)c->d_lights;
+    d.images = (const DevImage *)c->d_images;
+    d.texels = (const uint8_t *)c->d_texels;
+    d.n_objects = n; d.n_lights = s->n_lights; d.n_images = s->n_images; d.has_refraction = has_refr;
+    const ptx_camera &cam = s->cam;
+    for (int q = 0; q < 3; q++) { d.cam.e[q] = cam.e[q]; d.cam.w[q] = cam.w[q]; }
+    affine34(cam.C2W, d.cam.C2W);
+    d.cam.f = cam.f; d.cam.wl = cam.wl; d.cam.wt = cam.wt; d.cam.wsize = cam.wsize;
+    // fp = C2W (0,0,focus_distance,1), reference PathTracer.c:589-594
+    for (int r = 0; r < 3; r++)
+        d.cam.fp[r] = (cam.C2W[4 * r + 0] * 0.0) + (cam.C2W[4 * r + 1] * 0.0) + (cam.C2W[4 * r + 2] * cam.focus_distance) +
+                      (cam.C2W[4 * r + 3] * 1.0);
+    c->n_objects = n;
+    c->have_scene = true;
+    return PTX_OK;
+}
+
+static int fill_render(ptx_context *c, const ptx_render_params *p) {
+    if (!c || !p) return fail(PTX_EINVAL, "null argument");
+    if (!c->have_scene) return fail(PTX_ESTATE, "no scene uploaded");
+    if (p->sx < 2) return fail(PTX_EINVAL, "image size must be at least 2");
+    if (p->rng_mode != PTX_RNG_COUNTER) return fail(PTX_EINVAL, "only PTX_RNG_COUNTER runs on the GPU");
+    if (p->flags & ~7) return fail(PTX_EINVAL, "unknown flag bits");
+    int n_ranks = p->n_ranks <= 1 ? 1 : p->n_ranks;
+    if (n_ranks > 1 && (p->rank < 0 || p->rank >= n_ranks || p->band_rows <= 0))
+        return fail(PTX_EINVAL, "bad rank / n_ranks / band_rows");
+    if ((p->flags & PTX_USE_ES) && c->sc.n_lights == 0) return fail(PTX_EINVAL, "explicit sampling needs a light");
+    c->prm = *p;
+    DevRender &r = c->rp;
+    r.sx = p->sx; r.max_depth = p->max_depth;
+    r.rank = n_ranks > 1 ? p->rank : 0; r.n_ranks = n_ranks; r.band_rows = n_ranks > 1 ? p->band_rows : p->sx;
+    r.rows_owned = ptx_rows_owned(p->sx, r.rank, n_ranks, r.band_rows);
+    r.aperture = p->aperture; r.seed = p->seed;
+    r.du = c->sc.cam.wsize / (p->sx - 1);   // reference PathTracer.c:583-584
+    r.dv = -c->sc.cam.wsize / (p->sx - 1);
+    return PTX_OK;
+}
+
+extern "C" int ptx_render_begin(ptx_context *c, const ptx_render_params *p) {
+    int rc = fill_render(c, p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_render(c);
+    size_t npix = (size_t)c->rp.rows_owned * c->rp.sx;
+    if (npix == 0) npix = 1;
+    HIPCHK(hipMalloc((void **)&c->d_rgb, npix * 3 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c->d_wght, npix * sizeof(double)));
+    c->own_accum = true;
+    HIPCHK(hipMemsetAsync(c->d_rgb, 0, npix * 3 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, c->d_wght, npix, 1.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    c->rendering = true;
+    c->have_timing = false;
+    return PTX_OK;
+}
+
+extern "C" int ptx_render_begin_external(ptx_context *c, const ptx_render_params *p, double *d_rgb, double *d_wght) {
+    if (!d_rgb || !d_wght) return fail(PTX_EINVAL, "null accumulator");
+    int rc = fill_render(c, p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_render(c);
+    c->d_rgb = d_rgb;
+    c->d_wght = d_wght;
+    c->own_accum = false;
+    HIPCHK(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    c->rendering = true;
+    c->have_timing = false;
+    return PTX_OK;
+}
+
+template <typename F>
+static void dispatch_flags(int flags, F &&f) {
+    switch (flags & 7) {
+    case 0: f(std::integral_constant<int, 0>()); break;
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 3: f(std::integral_constant<int, 3>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 5: f(std::integral_constant<int, 5>()); break;
+    case 6: f(std::integral_constant<int, 6>()); break;
+    default: f(std::integral_constant<int, 7>()); break;
+    }
+}
+
+extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    if (k0 < 0 || nk < 0) return fail(PTX_EINVAL, "negative pass range");
+    if (nk == 0 || c->rp.rows_owned == 0) return PTX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int tiles_x = (c->rp.sx + 7) / 8, tiles_y = (c->rp.rows_owned + 7) / 8;
+    const long waves = (long)tiles_x * tiles_y;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    dispatch_flags(c->prm.flags, [&](auto fl) {
+        constexpr int F = decltype(fl)::value;
+        hipLaunchKernelGGL(k_render<F>, dim3(blocks), dim3(256), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
+                           c->d_wght, c->d_stats);
+    });
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    c->have_timing = true;
+    return PTX_OK;
+}
+
+extern "C" int ptx_sync(ptx_context *c) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+extern "C" int ptx_last_pass_ms(ptx_context *c, float *ms) {
+    if (!c || !ms) return fail(PTX_EINVAL, "null argument");
+    if (!c->have_timing) return fail(PTX_ESTATE, "no pass has been launched");
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PTX_OK;
+}
+
+extern "C" int ptx_accumulators(ptx_context *c, double **d_rgb, double **d_wght, int32_t *rows) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    if (d_rgb) *d_rgb = c->d_rgb;
+    if (d_wght) *d_wght = c->d_wght;
+    if (rows) *rows = c->rp.rows_owned;
+    return PTX_OK;
+}
+
+extern "C" int ptx_download(ptx_context *c, double *rgbIm, double *wght) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const DevRender &r = c->rp;
+    const size_t sx = r.sx;
+    // bands of consecutive local rows map to consecutive global rows
+    int local = 0;
+    while (local < r.rows_owned) {
+        int g0 = ptx_global_row(local, r.rank, r.n_ranks, r.band_rows);
+        int run = r.n_ranks <= 1 ? r.rows_owned : r.band_rows - local % r.band_rows;
+        if (run > r.rows_owned - local) run = r.rows_owned - local;
+        if (rgbIm)
+            HIPCHK(hipMemcpy(rgbIm + (size_t)g0 * sx * 3, c->d_rgb + (size_t)local * sx * 3, (size_t)run * sx * 3 * sizeof(double),
+                             hipMemcpyDeviceToHost));
+        if (wght)
+            HIPCHK(hipMemcpy(wght + (size_t)g0 * sx, c->d_wght + (size_t)local * sx, (size_t)run * sx * sizeof(double),
+                             hipMemcpyDeviceToHost));
+        local += run;
+    }
+    return PTX_OK;
+}
+
+extern "C" int ptx_get_stats(ptx_context *c, ptx_stats *st) {
+    if (!c || !st) return fail(PTX_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long h[4];
+    HIPCHK(hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    st->paths = h[0]; st->closest_hits = h[1]; st->shadow_rays = h[2]; st->rindex_oob = h[3];
+    return PTX_OK;
+}
+
+extern "C" int ptx_first_hit_device(ptx_context *c, const ptx_ray *d_rays, int64_t n, ptx_hit *d_hits) {
+    if (!c || (n > 0 && (!d_rays || !d_hits))) return fail(PTX_EINVAL, "null argument");
+    if (!c->have_scene) return fail(PTX_ESTATE, "no scene uploaded");
+    if (n < 0) return fail(PTX_EINVAL, "negative ray count");
+    if (n == 0) return PTX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_first_hit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays, (long)n,
+                       d_hits);
+    HIPCHK(hipGetLastError());
+    return PTX_OK;
+}
+
+extern "C" int ptx_first_hit(ptx_context *c, const ptx_ray *rays, int64_t n, ptx_hit *hits) {
+    if (!c || (n > 0 && (!rays || !hits))) return fail(PTX_EINVAL, "null argument");
+    if (!c->have_scene) return fail(PTX_ESTATE, "no scene uploaded");
+    if (n < 0) return fail(PTX_EINVAL, "negative ray count");
+    if (n == 0) return PTX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    ptx_ray *d_rays = nullptr;
+    ptx_hit *d_hits = nullptr;
+    HIPCHK(hipMalloc((void **)&d_rays, (size_t)n * sizeof(ptx_ray)));
+    if (hipMalloc((void **)&d_hits, (size_t)n * sizeof(ptx_hit)) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(PTX_ENOMEM, "ptx_first_hit: out of device memory");
+    }
+    int rc = PTX_OK;
+    if (hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(ptx_ray), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(PTX_EDEVICE, "ptx_first_hit: copy to device failed");
+    if (!rc) rc = ptx_first_hit_device(c, d_rays, n, d_hits);
+    if (!rc && hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(ptx_hit), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(PTX_EDEVICE, "ptx_first_hit: copy from device failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(PTX_EDEVICE, "ptx_first_hit: kernel failed");
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    return rc;
+}
+
+extern "C" int ptx_trace_paths(ptx_context *c, const ptx_render_params *p, const int32_t *pi, const int32_t *pj,
+                               const int32_t *pk, int64_t n, double *out) {
+    if (!c || !p || (n > 0 && (!pi || !pj || !pk || !out))) return fail(PTX_EINVAL, "null argument");
+    if (n < 0) return fail(PTX_EINVAL, "negative path count");
+    ptx_render_params saved_prm = c->prm;
+    DevRender saved_rp = c->rp;
+    ptx_render_params whole = *p;
+    whole.n_ranks = 1;
+    whole.rank = 0;
+    int rc = fill_render(c, &whole);
+    DevRender rp = c->rp;
+    c->prm = saved_prm;
+    c->rp = saved_rp;
+    if (rc) return rc;
+    if (n == 0) return PTX_OK;
+    for (int64_t q = 0; q < n; q++)
+        if (pi[q] < 0 || pi[q] >= p->sx || pj[q] < 0 || pj[q] >= p->sx || pk[q] < 0)
+            return fail(PTX_EINVAL, "ptx_trace_paths: pixel or sample out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int32_t *d_idx = nullptr;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_idx, (size_t)n * 3 * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_out, (size_t)n * 3 * sizeof(double)) != hipSuccess) {
+        (void)hipFree(d_idx);
+        return fail(PTX_ENOMEM, "ptx_trace_paths: out of device memory");
+    }
+    (void)hipMemcpyAsync(d_idx, pi, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    (void)hipMemcpyAsync(d_idx + n, pj, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    (void)hipMemcpyAsync(d_idx + 2 * n, pk, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    dispatch_flags(p->flags, [&](auto fl) {
+        constexpr int F = decltype(fl)::value;
+        hipLaunchKernelGGL(k_trace_paths<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, rp, d_idx,
+                           d_idx + n, d_idx + 2 * n, (long)n, d_out);
+    });
+    rc = PTX_OK;
+    if (hipGetLastError() != hipSuccess) rc = fail(PTX_EDEVICE, "ptx_trace_paths: launch failed");
+    if (!rc && hipMemcpyAsync(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(PTX_EDEVICE, "ptx_trace_paths: copy from device failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(PTX_EDEVICE, "ptx_trace_paths: kernel failed");
+    (void)hipFree(d_idx);
+    (void)hipFree(d_out);
+    return rc;
+}
