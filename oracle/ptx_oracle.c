@@ -751,6 +751,10 @@ static void light_sample(const ptx_object *ls, rng_t *rng, double *x, double *y,
     }
 }
 
+static int g_debug = 0;
+/* Prints the state after every bounce to stderr (debugging aid for the tests). */
+void orc_set_debug(int on) { g_debug = on; }
+
 /* PathTrace, PathTracer.c:253-484, with the tail recursion (:483) written
  * as a loop.  Returns the path's colour in col[3]. */
 static void path_trace(const orc_scene *sc, path_t *ps, int max_depth, int flags, rng_t *rng, double col[3],
@@ -876,6 +880,10 @@ static void path_trace(const orc_scene *sc, path_t *ps, int max_depth, int flags
         }
         ps->mem[6] = n.x; ps->mem[7] = n.y; ps->mem[8] = n.z; ps->mem[9] = n.w; /* ray->srcN = n, :482 */
         os = oi;
+        if (g_debug)
+            fprintf(stderr, "  orc depth %d os %d p0 %.17g %.17g %.17g d %.17g %.17g %.17g col %.6g %.6g %.6g I %.6g %.6g %.6g ridx %d\n",
+                    depth + 1, os, ps->p0.x, ps->p0.y, ps->p0.z, ps->d.x, ps->d.y, ps->d.z, COL(ps, 0), COL(ps, 1), COL(ps, 2),
+                    INT(ps, 0), INT(ps, 1), INT(ps, 2), ps->idx);
     }
     col[0] = INT(ps, 0);
     col[1] = INT(ps, 1);

@@ -49,6 +49,9 @@ void orc_render(const orc_scene *s, const ptx_render_params *prm, int k0, int nk
 void orc_trace_pixels(const orc_scene *s, const ptx_render_params *prm, const int32_t *pix_i, const int32_t *pix_j,
                       const int32_t *samp, int n, double *out);
 
+/* Debugging aid: per-bounce state on stderr. */
+void orc_set_debug(int on);
+
 /* Known-answer entry points; random numbers come from script[] in order. */
 void orc_kat_cos_weighted(const double n[3], const double *script, double out[3]);
 void orc_kat_hemisphere_reorient(const double n[3], const double v[3], double out[3]);

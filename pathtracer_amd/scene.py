@@ -39,6 +39,16 @@ class Scene:
             raise ValueError(f"{path}: trailing or missing bytes")
         return cls(objects.copy(), nodes.copy(), lights.copy(), images.copy(), texels.copy(), cam.copy())
 
+    @classmethod
+    def from_npz(cls, path):
+        """Scene arrays saved with numpy.savez (how the larger test scenes are stored)."""
+        z = np.load(path, allow_pickle=False)
+        return cls(z["objects"], z["nodes"], z["lights"], z["images"], z["texels"], z["camera"])
+
+    @classmethod
+    def load(cls, path):
+        return cls.from_npz(path) if path.endswith(".npz") else cls.from_file(path)
+
     def to_file(self, path):
         with open(path, "wb") as f:
             f.write(struct.pack("<QiiiiQ", abi.PTX_SCENE_MAGIC, len(self.objects), len(self.nodes), len(self.lights),
