@@ -3,11 +3,13 @@
 //
 // Each routine names the reference routine whose result it reproduces.  The
 // arithmetic is IEEE binary64 like the reference's, but it is not a
-// transcription: transforms use the 3x4 affine part only, trigonometric
-// round trips (atan2/acos followed by sin/cos of the same angle) are replaced
-// by the algebraic sine and cosine, and hit attributes are computed once for
-// the winning primitive instead of once per candidate.  Results agree with
-// the reference to rounding (about 1e-13 relative on lambda).
+// transcription: transforms use the 3x4 affine part only, uniformly scaled
+// spheres are intersected in world space, trigonometric round trips
+// (atan2/acos followed by sin/cos of the same angle) are replaced by the
+// algebraic sine and cosine, and hit attributes are computed once for the
+// winning primitive instead of once per candidate.  Results agree with the
+// reference to rounding (about 1e-11 relative on lambda for the radius-500
+// wall spheres of the Cornell scene, far inside the 1e-5 first-hit bar).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,6 +20,10 @@
 
 #define PT_PI 3.14159265354  // reference PathTracer.h:27 (not pi: the truncated value is part of the behaviour)
 #define PT_TOL 0.000000001   // reference PathTracer.h:28
+// 2*PT_PI/pi rounded to binary64: sin(2*PT_PI*u) = sinpi(PT_TWO_PI_OVER_PI*u)
+#define PT_TWO_PI_OVER_PI 0x1.ffffffffdd257p+0
+
+#define PTX_BLOCK 256  // threads per workgroup of every kernel that uses LaneStore
 
 struct V3 {
     double x, y, z;
@@ -37,17 +43,21 @@ __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_pat
 __device__ __forceinline__ double comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
 // ---------------------------------------------------------------- scene
-// Geometry record, 128 bytes, read either with a wave-uniform index (scalar
+// Geometry record, 160 bytes, read either with a wave-uniform index (scalar
 // loads) or per lane for the winning primitive.
 //   analytic primitives: m[0..11] = rows 0..2 of Tinv (3x4)
 //   triangles:           m[0..8]  = v1 v2 v3 (world space), m[9..11] = unit normal
+//   fast = 1: a sphere whose transform is a uniform scale plus a translation;
+//             c = centre, r2 = radius^2, inv_r = 1/radius
 struct DevGeom {
     int32_t type;
-    int32_t pad;
+    int32_t fast;
     double m[12];
-    double spare[3];
+    double c[3];
+    double r2, inv_r;
+    double pad[2];
 };
-static_assert(sizeof(DevGeom) == 128, "DevGeom layout");
+static_assert(sizeof(DevGeom) == 160, "DevGeom layout");
 
 // Shading record, 96 bytes, read per lane for the primitive that was hit.
 struct DevMat {
@@ -71,7 +81,6 @@ struct DevLight {
 
 struct DevImage {
     int32_t sx, sy, channels, pad;
-    double inv_div_unused;
     double divisor;
     uint64_t offset;
 };
@@ -112,6 +121,20 @@ struct Rng {
     __device__ __forceinline__ void skip(int n) { ctr += PTX_GOLDEN * (uint64_t)n; }
 };
 
+// --------------------------------------------------- per-lane LDS store
+// Cold per-lane state lives in LDS instead of registers: slot s of lane t is
+// word [s][t], so a wave touches 64 consecutive doubles (no bank conflicts)
+// and a lane can index its slots dynamically without going to scratch.
+//   slots 0..3   radiance accumulator r,g,b and weight of the lane's pixel
+//   slots 4..13  ray3D.r_index[0..9] (reference PathTracer.h:88)
+//   slots 14..16 ray3D.srcN x,y,z    (reference PathTracer.h:85)
+enum { LS_ACC = 0, LS_RINDEX = 4, LS_SRCN = 14, LS_SLOTS = 17 };
+struct LaneStore {
+    double *base;  // &lds[0][threadIdx.x]
+    __device__ __forceinline__ double get(int slot) const { return base[slot * PTX_BLOCK]; }
+    __device__ __forceinline__ void put(int slot, double v) const { base[slot * PTX_BLOCK] = v; }
+};
+
 // ------------------------------------------------------- transforms
 __device__ __forceinline__ V3 xform_point(const double *m, V3 p) {
     return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
@@ -132,7 +155,15 @@ __device__ __forceinline__ V3 xform_normal(const double *m, V3 n) {
 // (a value <= PT_TOL means "no usable hit") and, in `part`, which face or
 // section produced it.
 
-// sphereIntersect, reference utils_path.c:546-587
+// Smallest root > TOL of the sphere quadratic, reference utils_path.c:564-587.
+__device__ __forceinline__ double sphere_roots(double l1, double l2) {
+    double lam = -1.0;
+    if (l1 > PT_TOL) lam = l1;
+    if (l2 > PT_TOL && (l1 <= PT_TOL || l2 < l1)) lam = l2;
+    return lam;
+}
+
+// sphereIntersect, reference utils_path.c:546-587, in object space
 __device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double A = dot3(td, td), B = dot3(tp, td), C = dot3(tp, tp) - 1.0;
@@ -140,11 +171,20 @@ __device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
     if (disc < 0.0) return -1.0;
     double sq = sqrt(disc);
     double mb = -B / A, sa = sq / A;
-    double l1 = mb + sa, l2 = mb - sa;
-    double lam = -1.0;
-    if (l1 > PT_TOL) lam = l1;
-    if (l2 > PT_TOL && (l1 <= PT_TOL || l2 < l1)) lam = l2;
-    return lam;
+    return sphere_roots(mb + sa, mb - sa);
+}
+
+// The same quadratic for a uniformly scaled sphere, in world space: with
+// p' = (p0-c)/r and d' = d/r the reference's A, B, C are (d.d, oc.d,
+// oc.oc - r^2)/r^2 and the roots are unchanged.  inv_dd = 1/(d.d) is shared
+// by all spheres of one ray.
+__device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, V3 d, double dd, double inv_dd) {
+    V3 oc = mk(p0.x - g.c[0], p0.y - g.c[1], p0.z - g.c[2]);
+    double B = dot3(oc, d), C = dot3(oc, oc) - g.r2;
+    double disc = B * B - dd * C;
+    if (disc < 0.0) return -1.0;
+    double sq = sqrt(disc);
+    return sphere_roots((sq - B) * inv_dd, (-B - sq) * inv_dd);
 }
 
 // planeIntersect + planeHelper, reference utils_path.c:439-544
@@ -229,17 +269,6 @@ __device__ __forceinline__ double isect_triangle(const double *m, V3 p0, V3 d, i
     return -1.0;
 }
 
-__device__ __forceinline__ double isect_any(const DevGeom &g, V3 p0, V3 d, int &part) {
-    part = 0;
-    switch (g.type) {
-    case PTX_SPHERE: return isect_sphere(g.m, p0, d);
-    case PTX_PLANE: return isect_plane(g.m, p0, d);
-    case PTX_TRIANGLE: return isect_triangle(g.m, p0, d, part);
-    case PTX_CYL: return isect_cyl(g.m, p0, d, part);
-    default: return isect_box(g.m, p0, d, part);  // PTX_CUBE, PTX_ROOM
-    }
-}
-
 struct Hit {
     double lambda;
     int obj;
@@ -256,9 +285,23 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     h.lambda = INFINITY;
     h.obj = -1;
     h.part = 0;
+    const double dd = dot3(d, d);
+    const double inv_dd = 1.0 / dd;
     for (int k = 0; k < sc.n_objects; k++) {
-        int part;
-        double lam = isect_any(sc.geom[k], p0, d, part);
+        const DevGeom &g = sc.geom[k];
+        int part = 0;
+        double lam;
+        if (g.fast) {
+            lam = isect_sphere_uniform(g, p0, d, dd, inv_dd);
+        } else {
+            switch (g.type) {
+            case PTX_SPHERE: lam = isect_sphere(g.m, p0, d); break;
+            case PTX_PLANE: lam = isect_plane(g.m, p0, d); break;
+            case PTX_TRIANGLE: lam = isect_triangle(g.m, p0, d, part); break;
+            case PTX_CYL: lam = isect_cyl(g.m, p0, d, part); break;
+            default: lam = isect_box(g.m, p0, d, part); break;  // PTX_CUBE, PTX_ROOM
+            }
+        }
         if (k != os && lam > PT_TOL && lam < h.lambda) {
             h.lambda = lam;
             h.obj = k;
@@ -275,12 +318,23 @@ template <bool WANT_UV>
 __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 p0, V3 d, V3 &p, V3 &n, double &a,
                                            double &b) {
     const DevGeom &g = sc.geom[h.obj];
+    const int type = g.type;
     p = p0 + d * h.lambda;
     a = 0;
     b = 0;
-    if (g.type == PTX_TRIANGLE) {
+    if (type == PTX_TRIANGLE) {
         V3 nn = mk(g.m[9], g.m[10], g.m[11]);
         n = h.part ? nn * -1.0 : nn;
+        return;
+    }
+    if (g.fast) {
+        // canonical point (p-c)/r; Tinv^T is a multiple of the identity, so the normal is its direction
+        V3 pc = mk(p.x - g.c[0], p.y - g.c[1], p.z - g.c[2]) * g.inv_r;
+        n = norm3(pc);
+        if (WANT_UV) {
+            a = atan2(pc.y, pc.x) / (2 * PT_PI);
+            b = acos(pc.z) / PT_PI;
+        }
         return;
     }
     double m[12];
@@ -289,19 +343,19 @@ __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     V3 pc = tp + td * h.lambda;
     V3 nc;
-    if (g.type == PTX_SPHERE) {
+    if (type == PTX_SPHERE) {
         nc = norm3(pc);
         if (WANT_UV) {
             a = atan2(pc.y, pc.x) / (2 * PT_PI);
             b = acos(pc.z) / PT_PI;
         }
-    } else if (g.type == PTX_PLANE) {
+    } else if (type == PTX_PLANE) {
         nc = mk(0, 0, tp.z < 0 ? -1.0 : 1.0);
         if (WANT_UV) {
             a = (1 + pc.x) / 2;
             b = (1 + pc.y) / 2;
         }
-    } else if (g.type == PTX_CYL) {
+    } else if (type == PTX_CYL) {
         if (h.part == 0) {
             nc = mk(pc.x, pc.y, 0);
             if (WANT_UV) {
@@ -319,9 +373,9 @@ __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 
         const int f = h.part;
         const int ax = 2 - (f >> 1);
         double s = (f & 1) ? -1.0 : 1.0;
-        if (g.type == PTX_ROOM) s = -s;
+        if (type == PTX_ROOM) s = -s;
         nc = mk(ax == 0 ? s : 0.0, ax == 1 ? s : 0.0, ax == 2 ? s : 0.0);
-        if (WANT_UV && g.type == PTX_CUBE) {
+        if (WANT_UV && type == PTX_CUBE) {
             if (ax == 2) { a = (1 + pc.x) / 2; b = (1 + pc.y) / 2; }
             else if (ax == 1) { a = (1 + pc.x) / 2; b = (1 + pc.z) / 2; }
             else { a = (1 + pc.y) / 2; b = (1 + pc.z) / 2; }
@@ -403,13 +457,16 @@ __device__ __forceinline__ V3 normal_deform(const DevScene &sc, int img, double 
     return rotate_z_to(norm3(n), nd);
 }
 
+// sin and cos of 2*PT_PI*u for u in [0,1)
+__device__ __forceinline__ void sincos_turn(double u, double &s, double &c) { sincospi(PT_TWO_PI_OVER_PI * u, &s, &c); }
+
 // cosWeightedSample, reference utils_path.c:1224-1265 (two draws)
 __device__ __forceinline__ V3 cos_weighted_sample(V3 n, Rng &rng) {
     double u1 = rng.next();
     double r = sqrt(u1);
-    double theta = 2 * PT_PI * rng.next();
+    double u2 = rng.next();
     double s, c;
-    sincos(theta, &s, &c);
+    sincos_turn(u2, s, c);
     double x = r * c, y = r * s;
     double z = sqrt(1.0 - x * x - y * y);
     return rotate_z_to(n, mk(x, y, z));
@@ -421,10 +478,10 @@ __device__ __forceinline__ V3 cos_weighted_sample(V3 n, Rng &rng) {
 __device__ __forceinline__ V3 uniform_hemisphere_sample(V3 n, Rng &rng) {
     double c2 = 2 * rng.next() - 1;  // cos(angle_2)
     rng.skip(2);
-    double a1 = 2 * PT_PI * rng.next();
+    double u = rng.next();
     double s2 = sqrt(fmax(0.0, 1.0 - c2 * c2));  // sin(acos(c2))
     double s1, c1;
-    sincos(a1, &s1, &c1);
+    sincos_turn(u, s1, c1);
     V3 v = norm3(mk(s1 * s2, fabs(c2), -c1 * s2));
     // Rodrigues rotation taking (0,1,0) to n
     V3 up = mk(0, 1, 0);
@@ -438,35 +495,37 @@ __device__ __forceinline__ V3 uniform_hemisphere_sample(V3 n, Rng &rng) {
 __device__ __forceinline__ double random_normal(Rng &rng) {
     double ul = rng.next();
     double uc = rng.next();
-    return sqrt(-2 * log(ul)) * cos(2 * PT_PI * uc);
+    return sqrt(-2 * log(ul)) * cospi(PT_TWO_PI_OVER_PI * uc);
 }
 
 // ------------------------------------------------------------ path state
 // What survives from one bounce to the next: the live fields of the
 // reference's struct ray3D (PathTracer.h:76-90) plus PathTrace's Os and CEL
 // arguments.  The refraction-index stack and the normal of the previous
-// bounce are kept only for scenes with transmissive materials (rs[]).
+// bounce live in the lane's LDS slots.
 struct Path {
     V3 p0, d, col, I;
     Rng rng;
     int os, cel, depth;
-    int ridx;        // r_index_index
-    double rs[10];   // r_index[]
-    V3 srcN;
+    int ridx;  // r_index_index
+};
+
+struct Counters {
+    uint32_t closest, shadow, oob;
 };
 
 // Loads/stores of ray->r_index[k] as the reference performs them, including
 // the out-of-range indices refractRay can produce (PathTracer.c:101, :131),
 // which land on neighbouring fields of struct ray3D: k=-1 srcN.pw (always 1),
 // -2..-4 srcN.pz..px, -5..-7 I.B..R, -8..-10 col.B..R, 10 = r_index_index.
-__device__ inline double rindex_load(Path &ps, int k, uint32_t &oob) {
-    if (k >= 0 && k <= 9) return ps.rs[k];
+__device__ inline double rindex_load(Path &ps, const LaneStore &ls, int k, uint32_t &oob) {
+    if (k >= 0 && k <= 9) return ls.get(LS_RINDEX + k);
     oob++;
     switch (k) {
     case -1: return 1.0;
-    case -2: return ps.srcN.z;
-    case -3: return ps.srcN.y;
-    case -4: return ps.srcN.x;
+    case -2: return ls.get(LS_SRCN + 2);
+    case -3: return ls.get(LS_SRCN + 1);
+    case -4: return ls.get(LS_SRCN + 0);
     case -5: return ps.I.z;
     case -6: return ps.I.y;
     case -7: return ps.I.x;
@@ -477,8 +536,11 @@ __device__ inline double rindex_load(Path &ps, int k, uint32_t &oob) {
     default: return 1.0;
     }
 }
-__device__ inline void rindex_store(Path &ps, int k, double v, uint32_t &oob) {
-    if (k >= 0 && k <= 9) { ps.rs[k] = v; return; }
+__device__ inline void rindex_store(Path &ps, const LaneStore &ls, int k, double v, uint32_t &oob) {
+    if (k >= 0 && k <= 9) {
+        ls.put(LS_RINDEX + k, v);
+        return;
+    }
     oob++;
     switch (k) {
     case -5: ps.I.z = v; break;
@@ -499,23 +561,19 @@ __device__ __forceinline__ V3 reflect_dir(V3 d, V3 n) {
     return norm3(mk(d.x - 2 * dn * n.x, d.y - 2 * dn * n.y, d.z - 2 * dn * n.z));
 }
 
-struct Counters {
-    uint32_t closest, shadow, oob;
-};
-
 // refractRay, reference PathTracer.c:74-140.  n is normalised in place like
 // the reference's *normal.
-__device__ inline void refract_ray(Path &ps, V3 p, V3 &n, const DevMat &mt, Counters &cnt) {
-    double n1 = rindex_load(ps, ps.ridx, cnt.oob);
-    double n2 = mt.r_index;
+__device__ inline void refract_ray(Path &ps, const LaneStore &ls, V3 p, V3 &n, double obj_r_index, Counters &cnt) {
+    double n1 = rindex_load(ps, ls, ps.ridx, cnt.oob);
+    double n2 = obj_r_index;
     double r = n1 / n2;
     bool leaving = false;
     ps.d = norm3(ps.d);
     n = norm3(n);
     V3 rn = n;
     if (!(dot3(ps.d, n) < 0)) {
-        n1 = mt.r_index;
-        n2 = rindex_load(ps, ps.ridx - 1, cnt.oob);
+        n1 = obj_r_index;
+        n2 = rindex_load(ps, ls, ps.ridx - 1, cnt.oob);
         r = n1 / n2;
         rn = n * -1.0;
         leaving = true;
@@ -536,7 +594,7 @@ __device__ inline void refract_ray(Path &ps, V3 p, V3 &n, const DevMat &mt, Coun
         ps.ridx = ps.ridx - 1;
     } else {
         ps.ridx = ps.ridx + 1;
-        rindex_store(ps, ps.ridx, mt.r_index, cnt.oob);
+        rindex_store(ps, ls, ps.ridx, obj_r_index, cnt.oob);
     }
     ps.d = norm3(ps.d * r + rn * (r * c - sqrt(disc)));
 }
@@ -544,7 +602,7 @@ __device__ inline void refract_ray(Path &ps, V3 p, V3 &n, const DevMat &mt, Coun
 // Primary ray of pixel (i,j), sample k: reference PathTracer.c:625-641 with
 // sampleLensPoint (:142-158), focusRay (:160-195), initRay
 // (utils_path.h:211-230).  Two draws are consumed whatever the aperture.
-__device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, int i, int j, int k, bool track_rindex,
+__device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, const LaneStore &ls, int i, int j, int k,
                                    Path &ps) {
     ps.rng.ctr = ptx_path_key(rp.seed, (uint64_t)j * (uint64_t)rp.sx + (uint64_t)i, (uint64_t)k);
     const DevCamera &cam = sc.cam;
@@ -552,9 +610,9 @@ __device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, int 
     V3 pl = pc;
     if (rp.aperture != 0) {
         double r = rp.aperture * sqrt(ps.rng.next());
-        double theta = ps.rng.next() * 2 * PT_PI;
+        double u = ps.rng.next();
         double s, c;
-        sincos(theta, &s, &c);
+        sincos_turn(u, s, c);
         pl.x = pc.x + r * c;
         pl.y = pc.y + r * s;
     } else {
@@ -575,11 +633,13 @@ __device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, int 
     ps.cel = 0;
     ps.depth = 1;
     ps.ridx = 0;
-    if (track_rindex) {
+    if (sc.has_refraction) {
+        ls.put(LS_RINDEX + 0, 1.0);
 #pragma unroll
-        for (int q = 0; q < 10; q++) ps.rs[q] = 0;
-        ps.rs[0] = 1;
-        ps.srcN = mk(0, 0, 1);
+        for (int q = 1; q < 10; q++) ls.put(LS_RINDEX + q, 0.0);
+        ls.put(LS_SRCN + 0, 0.0);
+        ls.put(LS_SRCN + 1, 0.0);
+        ls.put(LS_SRCN + 2, 1.0);
     }
 }
 
@@ -594,11 +654,10 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
     }
     if (ls.type == PTX_SPHERE) {
         double v1 = rng.next(), v2 = rng.next();
-        double theta = 2 * PT_PI * v1;
         double cphi = 2 * v2 - 1;  // cos(acos(.))
         double sphi = sqrt(fmax(0.0, 1.0 - cphi * cphi));
         double s, c;
-        sincos(theta, &s, &c);
+        sincos_turn(v1, s, c);
         return xform_point(ls.T, mk(c * sphi, s * sphi, cphi));
     }
     if (ls.type == PTX_CYL) rng.skip(2);
@@ -606,23 +665,25 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
 }
 
 // One invocation of PathTrace (reference PathTracer.c:253-484) for a live
-// path: returns true when the path has ended, its colour then being ps.I.
+// path whose depth does not exceed MAX_DEPTH: returns true when the path has
+// ended, its colour then being ps.I.  The reference's depth test at the top
+// of the next invocation (:273) is applied at the end of this one, so a path
+// that has used up its depth ends without another trip through the loop.
 template <int FLAGS>
-__device__ inline bool bounce(const DevScene &sc, const DevRender &rp, Path &ps, Counters &cnt) {
-    if (ps.depth > rp.max_depth) return true;
+__device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt) {
     ps.d = norm3(ps.d);
     cnt.closest++;
     Hit h = closest_hit_all(sc, ps.p0, ps.d, ps.os);
     if (h.obj < 0) return true;
-    const DevMat mt = sc.mat[h.obj];
+    const DevMat &mt = sc.mat[h.obj];
+    const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
     V3 p, n;
     double a, b;
-    const bool want_uv = (mt.tex_img >= 0) | (mt.normal_img >= 0) | (mt.alpha_img >= 0);
-    if (want_uv) finish_hit<true>(sc, h, ps.p0, ps.d, p, n, a, b);
+    if ((tex_img & normal_img & alpha_img) >= 0) finish_hit<true>(sc, h, ps.p0, ps.d, p, n, a, b);  // any index >= 0
     else finish_hit<false>(sc, h, ps.p0, ps.d, p, n, a, b);
     double R = mt.col[0], G = mt.col[1], B = mt.col[2];
-    if (mt.tex_img >= 0) tex_map(sc, mt.tex_img, a, b, R, G, B);
-    if (mt.normal_img >= 0) n = normal_deform(sc, mt.normal_img, a, b, n);
+    if (tex_img >= 0) tex_map(sc, tex_img, a, b, R, G, B);
+    if (normal_img >= 0) n = normal_deform(sc, normal_img, a, b, n);
     if (mt.is_light) {
         if (!ps.cel) ps.I = mk(ps.I.x + ps.col.x * R, ps.I.y + ps.col.y * G, ps.I.z + ps.col.z * B);
         return true;
@@ -636,12 +697,13 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, Path &ps,
     }
     if (rr > ps.rng.next()) return true;
     double diffusivity = mt.diffPct, reflectivity = mt.reflPct, transparency = mt.tranPct;
-    if (mt.alpha_img >= 0) {
-        transparency = alpha_map(sc, mt.alpha_img, a, b);
-        reflectivity = (1 - transparency) * mt.reflPct / (mt.reflPct + mt.diffPct);
-        diffusivity = (1 - transparency) * mt.diffPct / (mt.reflPct + mt.diffPct);
+    if (alpha_img >= 0) {
+        transparency = alpha_map(sc, alpha_img, a, b);
+        double both = reflectivity + diffusivity;
+        reflectivity = (1 - transparency) * mt.reflPct / both;
+        diffusivity = (1 - transparency) * mt.diffPct / both;
     }
-    const double inv_keep = 1.0 / (1 - rr);
+    const double inv_keep = (FLAGS & PTX_USE_RR) ? 1.0 / (1 - rr) : 1.0;
     double dice = ps.rng.next();
     int next_os = h.obj;
     if (dice <= diffusivity) {
@@ -649,12 +711,12 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, Path &ps,
         double scale;
         if (FLAGS & PTX_USE_IS) {
             dir = norm3(cos_weighted_sample(n, ps.rng));
-            scale = 1.0;  // (n.dir) / probability with probability = n.dir, reference PathTracer.c:364, :390
+            scale = inv_keep;  // (n.dir) / probability with probability = n.dir, reference PathTracer.c:364, :390
         } else {
             dir = uniform_hemisphere_sample(n, ps.rng);
-            scale = dot3(n, dir);
+            scale = dot3(n, dir) * inv_keep;
         }
-        ps.col = mk(ps.col.x * (R * scale * inv_keep), ps.col.y * (G * scale * inv_keep), ps.col.z * (B * scale * inv_keep));
+        ps.col = mk(ps.col.x * (R * scale), ps.col.y * (G * scale), ps.col.z * (B * scale));
         ps.p0 = p;
         ps.d = dir;
         if (FLAGS & PTX_USE_ES) {
@@ -666,46 +728,51 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, Path &ps,
                 acc += sc.lights[li].weight;
             }
             V3 lp = light_sample(sc.lights[li], ps.rng);
-            V3 ed = norm3(lp - p);
+            V3 dl = lp - p;
+            double d2 = dot3(dl, dl);
+            V3 ed = dl * (1.0 / sqrt(d2));
             cnt.shadow++;
             Hit sh = closest_hit_all(sc, p, ed, h.obj);
-            bool lit = false;
+            int lit = 0;
             if (sh.obj >= 0) {
-                const DevMat lm = sc.mat[sh.obj];
+                const DevMat &lm = sc.mat[sh.obj];
                 if (lm.is_light) {
                     V3 lpnt, ln;
                     double la, lb;
                     finish_hit<false>(sc, sh, p, ed, lpnt, ln, la, lb);
-                    V3 dl = lp - p;
-                    double d2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z;
                     double weight2 = dot3(n, ed) * -dot3(ln, ed);
                     double wgt = (lm.surfaceArea * weight2) / d2;
                     wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
-                    ps.I = mk(ps.I.x + ps.col.x * R * lm.col[0] * wgt * inv_keep,
-                              ps.I.y + ps.col.y * G * lm.col[1] * wgt * inv_keep,
-                              ps.I.z + ps.col.z * B * lm.col[2] * wgt * inv_keep);
-                    lit = true;
+                    wgt *= inv_keep;
+                    ps.I = mk(ps.I.x + ps.col.x * R * lm.col[0] * wgt, ps.I.y + ps.col.y * G * lm.col[1] * wgt,
+                              ps.I.z + ps.col.z * B * lm.col[2] * wgt);
+                    lit = 1;
                 }
             }
-            ps.cel = lit ? 1 : 0;
+            ps.cel = lit;
         }
     } else if (dice <= diffusivity + reflectivity) {
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         n = norm3(n);
         ps.d = reflect_dir(ps.d, n);
         ps.p0 = p;
-        if (mt.refl_sig > 0) {
-            ps.d.x += mt.refl_sig * random_normal(ps.rng);
-            ps.d.y += mt.refl_sig * random_normal(ps.rng);
-            ps.d.z += mt.refl_sig * random_normal(ps.rng);
+        const double sig = mt.refl_sig;
+        if (sig > 0) {
+            ps.d.x += sig * random_normal(ps.rng);
+            ps.d.y += sig * random_normal(ps.rng);
+            ps.d.z += sig * random_normal(ps.rng);
         }
     } else if (dice <= diffusivity + reflectivity + transparency) {
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        refract_ray(ps, p, n, mt, cnt);
+        refract_ray(ps, ls, p, n, mt.r_index, cnt);
         next_os = -1;
     }
-    if (sc.has_refraction) ps.srcN = n;
+    if (sc.has_refraction) {
+        ls.put(LS_SRCN + 0, n.x);
+        ls.put(LS_SRCN + 1, n.y);
+        ls.put(LS_SRCN + 2, n.z);
+    }
     ps.os = next_os;
     ps.depth++;
-    return false;
+    return ps.depth > rp.max_depth;
 }

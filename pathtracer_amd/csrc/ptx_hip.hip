@@ -22,12 +22,19 @@
 #include "ptx_device.h"
 #include "ptx_hip.h"
 
+#ifndef PTX_RENDER_WAVES_PER_EU
+#define PTX_RENDER_WAVES_PER_EU 2
+#endif
+
 // ------------------------------------------------------------------ kernels
 template <int FLAGS>
-__global__ void __launch_bounds__(256) k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb,
-                                                 double *__restrict__ wght, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
+    k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
+             unsigned long long *__restrict__ stats) {
+    __shared__ double lds[LS_SLOTS][PTX_BLOCK];
+    const LaneStore ls{&lds[0][threadIdx.x]};
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave = blockIdx.x * (PTX_BLOCK >> 6) + (threadIdx.x >> 6);
     const int tiles_x = (rp.sx + 7) >> 3;
     const int tx = wave % tiles_x, ty = wave / tiles_x;
     const int i = tx * 8 + (lane & 7);
@@ -36,35 +43,38 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, DevRender rp, int k
     const int j = inside ? ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows) : 0;
     const size_t pix = inside ? (size_t)jl * rp.sx + i : 0;
 
-    double acc_r = 0, acc_g = 0, acc_b = 0, wt = 1;
     if (inside) {
-        acc_r = rgb[pix * 3 + 0];
-        acc_g = rgb[pix * 3 + 1];
-        acc_b = rgb[pix * 3 + 2];
-        wt = wght[pix];
+        ls.put(LS_ACC + 0, rgb[pix * 3 + 0]);
+        ls.put(LS_ACC + 1, rgb[pix * 3 + 1]);
+        ls.put(LS_ACC + 2, rgb[pix * 3 + 2]);
+        ls.put(LS_ACC + 3, wght[pix]);
     }
     Counters cnt = {0, 0, 0};
     uint32_t paths = 0;
     Path ps;
     bool alive = false;
     int k = inside ? k0 : k1;
-    const bool track = sc.has_refraction != 0;
     for (;;) {
+        bool ended = false;
         if (!alive && k < k1) {
-            primary_ray(sc, rp, i, j, k, track, ps);
+            primary_ray(sc, rp, ls, i, j, k, ps);
             alive = true;
+            ended = rp.max_depth < 1;  // reference PathTracer.c:273 with depth = 1
         }
         if (__ballot(alive) == 0ULL) break;
         if (alive) {
-            if (bounce<FLAGS>(sc, rp, ps, cnt)) {
+            if (!ended) ended = bounce<FLAGS>(sc, rp, ls, ps, cnt);
+            if (ended) {
                 // fold, reference PathTracer.c:646-652
+                double wt = ls.get(LS_ACC + 3);
                 double f = exp2(-log(wt));
-                acc_r += ps.I.x * f;
-                acc_g += ps.I.y * f;
-                acc_b += ps.I.z * f;
+                ls.put(LS_ACC + 0, ls.get(LS_ACC + 0) + ps.I.x * f);
+                ls.put(LS_ACC + 1, ls.get(LS_ACC + 1) + ps.I.y * f);
+                ls.put(LS_ACC + 2, ls.get(LS_ACC + 2) + ps.I.z * f);
                 wt += ps.I.x;
                 wt += ps.I.y;
                 wt += ps.I.z;
+                ls.put(LS_ACC + 3, wt);
                 alive = false;
                 k++;
                 paths++;
@@ -72,10 +82,10 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, DevRender rp, int k
         }
     }
     if (inside) {
-        rgb[pix * 3 + 0] = acc_r;
-        rgb[pix * 3 + 1] = acc_g;
-        rgb[pix * 3 + 2] = acc_b;
-        wght[pix] = wt;
+        rgb[pix * 3 + 0] = ls.get(LS_ACC + 0);
+        rgb[pix * 3 + 1] = ls.get(LS_ACC + 1);
+        rgb[pix * 3 + 2] = ls.get(LS_ACC + 2);
+        wght[pix] = ls.get(LS_ACC + 3);
     }
     // one set of atomics per wave
     unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
@@ -94,15 +104,19 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, DevRender rp, int k
 }
 
 template <int FLAGS>
-__global__ void __launch_bounds__(256) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
-                                                      const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
-                                                      long n, double *__restrict__ out) {
+__global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
+                                                            const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
+                                                            long n, double *__restrict__ out) {
+    __shared__ double lds[LS_SLOTS][PTX_BLOCK];
+    const LaneStore ls{&lds[0][threadIdx.x]};
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     Counters cnt = {0, 0, 0};
     Path ps;
-    primary_ray(sc, rp, pi[q], pj[q], pk[q], sc.has_refraction != 0, ps);
-    while (!bounce<FLAGS>(sc, rp, ps, cnt)) {
+    primary_ray(sc, rp, ls, pi[q], pj[q], pk[q], ps);
+    if (rp.max_depth >= 1) {
+        while (!bounce<FLAGS>(sc, rp, ls, ps, cnt)) {
+        }
     }
     out[3 * q + 0] = ps.I.x;
     out[3 * q + 1] = ps.I.y;
@@ -278,6 +292,15 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
             tri_normal(o, &g.m[9]);
         } else {
             affine34(o.Tinv, g.m);
+            // a sphere under uniform scale + translation (T exactly diag(r,r,r | c)) is intersected in world space
+            const double *T = o.T;
+            bool diag = T[1] == 0 && T[2] == 0 && T[4] == 0 && T[6] == 0 && T[8] == 0 && T[9] == 0;
+            if (o.type == PTX_SPHERE && diag && T[0] > 0 && T[0] == T[5] && T[0] == T[10]) {
+                g.fast = 1;
+                g.c[0] = T[3]; g.c[1] = T[7]; g.c[2] = T[11];
+                g.r2 = T[0] * T[0];
+                g.inv_r = 1.0 / T[0];
+            }
         }
         DevMat &m = mat[k];
         memset(&m, 0, sizeof(m));
