@@ -36,9 +36,28 @@ __device__ __forceinline__ double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.
 __device__ __forceinline__ V3 cross3(V3 u, V3 v) {
     return mk(u.y * v.z - v.y * u.z, v.x * u.z - u.x * v.z, u.x * v.y - v.x * u.y);
 }
+// 1/x for finite non-zero x: hardware estimate plus two Newton steps (error about 1 ulp).  Not for
+// divisors that may be zero: the reference's divisions by zero yield infinities that later tests rely on.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// sqrt(x) for x >= 0 (0 for x == 0), from the hardware reciprocal square root plus Goldschmidt steps.
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
-    double l = 1.0 / sqrt(dot3(v, v));
-    return v * l;
+    return v * rsqrt(dot3(v, v));
 }
 __device__ __forceinline__ double comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
@@ -183,7 +202,7 @@ __device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, 
     double B = dot3(oc, d), C = dot3(oc, oc) - g.r2;
     double disc = B * B - dd * C;
     if (disc < 0.0) return -1.0;
-    double sq = sqrt(disc);
+    double sq = fast_sqrt(disc);
     return sphere_roots((sq - B) * inv_dd, (-B - sq) * inv_dd);
 }
 
@@ -286,7 +305,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     h.obj = -1;
     h.part = 0;
     const double dd = dot3(d, d);
-    const double inv_dd = 1.0 / dd;
+    const double inv_dd = fast_rcp(dd);
     for (int k = 0; k < sc.n_objects; k++) {
         const DevGeom &g = sc.geom[k];
         int part = 0;
@@ -436,7 +455,7 @@ __device__ __forceinline__ V3 rotate_z_to(V3 n, V3 v) {
     double h2 = n.x * n.x + n.y * n.y;
     double ct = 1.0, st = 0.0;  // atan2(0,0) = 0
     if (h2 > 0) {
-        double ih = 1.0 / sqrt(h2);
+        double ih = rsqrt(h2);
         ct = n.x * ih;
         st = n.y * ih;
     } else if (n.x < 0 || (n.x == 0 && signbit(n.x))) {
@@ -703,7 +722,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         reflectivity = (1 - transparency) * mt.reflPct / both;
         diffusivity = (1 - transparency) * mt.diffPct / both;
     }
-    const double inv_keep = (FLAGS & PTX_USE_RR) ? 1.0 / (1 - rr) : 1.0;
+    const double inv_keep = (FLAGS & PTX_USE_RR) ? fast_rcp(1 - rr) : 1.0;
     double dice = ps.rng.next();
     int next_os = h.obj;
     if (dice <= diffusivity) {
@@ -730,7 +749,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             V3 lp = light_sample(sc.lights[li], ps.rng);
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
-            V3 ed = dl * (1.0 / sqrt(d2));
+            V3 ed = dl * rsqrt(d2);
             cnt.shadow++;
             Hit sh = closest_hit_all(sc, p, ed, h.obj);
             int lit = 0;
@@ -741,7 +760,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                     double la, lb;
                     finish_hit<false>(sc, sh, p, ed, lpnt, ln, la, lb);
                     double weight2 = dot3(n, ed) * -dot3(ln, ed);
-                    double wgt = (lm.surfaceArea * weight2) / d2;
+                    double wgt = (lm.surfaceArea * weight2) * fast_rcp(d2);
                     wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
                     wgt *= inv_keep;
                     ps.I = mk(ps.I.x + ps.col.x * R * lm.col[0] * wgt, ps.I.y + ps.col.y * G * lm.col[1] * wgt,

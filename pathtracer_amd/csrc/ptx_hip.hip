@@ -23,7 +23,7 @@
 #include "ptx_hip.h"
 
 #ifndef PTX_RENDER_WAVES_PER_EU
-#define PTX_RENDER_WAVES_PER_EU 2
+#define PTX_RENDER_WAVES_PER_EU 3
 #endif
 
 // ------------------------------------------------------------------ kernels
