@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ptx_bvh.h"
 #include "ptx_rng.h"
 #include "ptx_scene.h"
 
@@ -111,13 +112,20 @@ struct DevCamera {
     double fp[3];  // C2W * (0,0,focus_distance,1), reference PathTracer.c:589-594
 };
 
+// Closest-hit queries test two sets of primitives: a short list that every ray tests in turn (all primitives of a
+// small scene; in a large scene the few whose boxes are far bigger than the rest, which would spoil a hierarchy),
+// and the remaining primitives through the bounding-volume hierarchy.
 struct DevScene {
-    const DevGeom *geom;
+    const DevGeom *geom;      // every primitive, scene order (= the reference's visiting order)
     const DevMat *mat;
+    const DevGeom *list_geom; // the always-tested primitives, ascending scene index
+    const int32_t *list_ids;  // their scene indices
+    const PtxBvhNode *bvh;    // hierarchy over the others, or nullptr
     const DevLight *lights;
     const DevImage *images;
     const uint8_t *texels;
-    int32_t n_objects, n_lights, n_images, has_refraction;
+    int32_t n_objects, n_list, n_bvh_nodes;
+    int32_t n_lights, n_images, has_refraction;
     DevCamera cam;
 };
 
@@ -294,11 +302,28 @@ struct Hit {
     int part;
 };
 
-// findFirstHit (reference PathTracer.c:198-251) by exhaustive search: every
-// primitive is tested, the smallest lambda > TOL wins, the earlier primitive
-// wins ties (primitives are stored in the reference's visiting order).  The
-// loop index is wave-uniform, so the geometry records arrive through scalar
-// loads and no lane diverges on the primitive type.
+// lambda of one primitive for one ray (dd = d.d, inv_dd = 1/dd)
+__device__ __forceinline__ double isect_any(const DevGeom &g, V3 p0, V3 d, double dd, double inv_dd, int &part) {
+    part = 0;
+    if (g.fast) return isect_sphere_uniform(g, p0, d, dd, inv_dd);
+    switch (g.type) {
+    case PTX_SPHERE: return isect_sphere(g.m, p0, d);
+    case PTX_PLANE: return isect_plane(g.m, p0, d);
+    case PTX_TRIANGLE: return isect_triangle(g.m, p0, d, part);
+    case PTX_CYL: return isect_cyl(g.m, p0, d, part);
+    default: return isect_box(g.m, p0, d, part);  // PTX_CUBE, PTX_ROOM
+    }
+}
+
+// findFirstHit (reference PathTracer.c:198-251): the smallest lambda > TOL wins and, between equal lambdas, the
+// primitive the reference visits first (the lower scene index).
+//  - The always-tested list is walked with a wave-uniform index, so its records arrive through scalar loads and
+//    no lane diverges on the primitive type.
+//  - The hierarchy is walked per lane without a stack (PtxBvhNode::skip).  A node is entered if the ray's slab
+//    interval is not empty, does not end behind the origin and does not start beyond the best hit so far; the
+//    reference's box_intersect (magic.c:457-474) is the same slab test without the last condition.  A relative
+//    slack keeps rounding from rejecting a box the reference would enter.
+template <bool USE_BVH>
 __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os) {
     Hit h;
     h.lambda = INFINITY;
@@ -306,25 +331,43 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     h.part = 0;
     const double dd = dot3(d, d);
     const double inv_dd = fast_rcp(dd);
-    for (int k = 0; k < sc.n_objects; k++) {
-        const DevGeom &g = sc.geom[k];
-        int part = 0;
-        double lam;
-        if (g.fast) {
-            lam = isect_sphere_uniform(g, p0, d, dd, inv_dd);
-        } else {
-            switch (g.type) {
-            case PTX_SPHERE: lam = isect_sphere(g.m, p0, d); break;
-            case PTX_PLANE: lam = isect_plane(g.m, p0, d); break;
-            case PTX_TRIANGLE: lam = isect_triangle(g.m, p0, d, part); break;
-            case PTX_CYL: lam = isect_cyl(g.m, p0, d, part); break;
-            default: lam = isect_box(g.m, p0, d, part); break;  // PTX_CUBE, PTX_ROOM
-            }
-        }
-        if (k != os && lam > PT_TOL && lam < h.lambda) {
+    for (int k = 0; k < sc.n_list; k++) {
+        int part;
+        const int id = USE_BVH ? sc.list_ids[k] : k;
+        double lam = isect_any(sc.list_geom[k], p0, d, dd, inv_dd, part);
+        if (id != os && lam > PT_TOL && lam < h.lambda) {
             h.lambda = lam;
-            h.obj = k;
+            h.obj = id;
             h.part = part;
+        }
+    }
+    if (USE_BVH) {
+        const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;  // IEEE division: a zero component gives +-inf
+        int node = 0;
+        const int n_nodes = sc.n_bvh_nodes;
+        while (node < n_nodes) {
+            const PtxBvhNode &nd = sc.bvh[node];
+            double t0 = (nd.box[0] - p0.x) * ix, t1 = (nd.box[1] - p0.x) * ix;
+            double t2 = (nd.box[2] - p0.y) * iy, t3 = (nd.box[3] - p0.y) * iy;
+            double t4 = (nd.box[4] - p0.z) * iz, t5 = (nd.box[5] - p0.z) * iz;
+            double lmin = fmax(fmax(fmin(t0, t1), fmin(t2, t3)), fmin(t4, t5));
+            double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
+            double slack = 1e-12 * (fabs(lmin) + fabs(lmax));
+            int next = nd.skip;
+            if (!(lmin > lmax + slack) && !(lmax < -slack) && !(lmin > h.lambda + slack)) {
+                const int id = nd.obj;
+                next = node + 1;
+                if (id >= 0 && id != os) {
+                    int part;
+                    double lam = isect_any(sc.geom[id], p0, d, dd, inv_dd, part);
+                    if (lam > PT_TOL && (lam < h.lambda || (lam == h.lambda && id < h.obj))) {
+                        h.lambda = lam;
+                        h.obj = id;
+                        h.part = part;
+                    }
+                }
+            }
+            node = next;
         }
     }
     return h;
@@ -688,11 +731,11 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
 // ended, its colour then being ps.I.  The reference's depth test at the top
 // of the next invocation (:273) is applied at the end of this one, so a path
 // that has used up its depth ends without another trip through the loop.
-template <int FLAGS>
+template <int FLAGS, bool USE_BVH>
 __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt) {
     ps.d = norm3(ps.d);
     cnt.closest++;
-    Hit h = closest_hit_all(sc, ps.p0, ps.d, ps.os);
+    Hit h = closest_hit_all<USE_BVH>(sc, ps.p0, ps.d, ps.os);
     if (h.obj < 0) return true;
     const DevMat &mt = sc.mat[h.obj];
     const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
@@ -751,7 +794,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             double d2 = dot3(dl, dl);
             V3 ed = dl * rsqrt(d2);
             cnt.shadow++;
-            Hit sh = closest_hit_all(sc, p, ed, h.obj);
+            Hit sh = closest_hit_all<USE_BVH>(sc, p, ed, h.obj);
             int lit = 0;
             if (sh.obj >= 0) {
                 const DevMat &lm = sc.mat[sh.obj];

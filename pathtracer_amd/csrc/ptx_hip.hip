@@ -13,6 +13,8 @@
 // its lanes follow similar paths.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -27,7 +29,7 @@
 #endif
 
 // ------------------------------------------------------------------ kernels
-template <int FLAGS>
+template <int FLAGS, bool USE_BVH>
 __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
              unsigned long long *__restrict__ stats) {
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
         }
         if (__ballot(alive) == 0ULL) break;
         if (alive) {
-            if (!ended) ended = bounce<FLAGS>(sc, rp, ls, ps, cnt);
+            if (!ended) ended = bounce<FLAGS, USE_BVH>(sc, rp, ls, ps, cnt);
             if (ended) {
                 // fold, reference PathTracer.c:646-652
                 double wt = ls.get(LS_ACC + 3);
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     }
 }
 
-template <int FLAGS>
+template <int FLAGS, bool USE_BVH>
 __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
                                                             const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
                                                             long n, double *__restrict__ out) {
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRende
     Path ps;
     primary_ray(sc, rp, ls, pi[q], pj[q], pk[q], ps);
     if (rp.max_depth >= 1) {
-        while (!bounce<FLAGS>(sc, rp, ls, ps, cnt)) {
+        while (!bounce<FLAGS, USE_BVH>(sc, rp, ls, ps, cnt)) {
         }
     }
     out[3 * q + 0] = ps.I.x;
@@ -123,13 +125,14 @@ __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRende
     out[3 * q + 2] = ps.I.z;
 }
 
+template <bool USE_BVH>
 __global__ void __launch_bounds__(256) k_first_hit(DevScene sc, const ptx_ray *__restrict__ rays, long n,
                                                     ptx_hit *__restrict__ hits) {
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     ptx_ray r = rays[q];
     V3 p0 = mk(r.p0[0], r.p0[1], r.p0[2]), d = mk(r.d[0], r.d[1], r.d[2]);
-    Hit h = closest_hit_all(sc, p0, d, r.os);
+    Hit h = closest_hit_all<USE_BVH>(sc, p0, d, r.os);
     ptx_hit o;
     o.lambda = -1;
     o.obj = -1;
@@ -178,6 +181,8 @@ struct ptx_context {
     bool have_scene = false;
     DevScene sc{};
     void *d_geom = nullptr, *d_mat = nullptr, *d_lights = nullptr, *d_images = nullptr, *d_texels = nullptr;
+    void *d_list_geom = nullptr, *d_list_ids = nullptr, *d_bvh = nullptr;
+    bool use_bvh = false;
     int n_objects = 0;
     // render
     bool rendering = false;
@@ -189,8 +194,10 @@ struct ptx_context {
 };
 
 static void free_scene(ptx_context *c) {
-    for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels}) (void)hipFree(q);
+    for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels, c->d_list_geom, c->d_list_ids, c->d_bvh})
+        (void)hipFree(q);
     c->d_geom = c->d_mat = c->d_lights = c->d_images = c->d_texels = nullptr;
+    c->d_list_geom = c->d_list_ids = c->d_bvh = nullptr;
     c->have_scene = false;
 }
 static void free_render(ptx_context *c) {
@@ -331,6 +338,55 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         images[q].sx = im.sx; images[q].sy = im.sy; images[q].channels = im.channels;
         images[q].divisor = im.divisor; images[q].offset = im.data_offset;
     }
+    // Which primitives every ray tests directly, and which go into the hierarchy.  A small scene is tested
+    // exhaustively.  In a large one, primitives whose box is far larger than the typical box (walls, floors,
+    // lights around a mesh) stay on the direct list: inside a hierarchy their boxes would cover everything.
+    std::vector<int32_t> list_ids;
+    std::vector<int> bvh_ids;
+    const int SMALL_SCENE = 48, MAX_DIRECT = 96;
+    if (n <= SMALL_SCENE) {
+        for (int k = 0; k < n; k++) list_ids.push_back(k);
+    } else {
+        std::vector<double> extent(n);
+        for (int k = 0; k < n; k++) {
+            const double *b = s->objects[k].box;
+            extent[k] = (b[1] - b[0]) + (b[3] - b[2]) + (b[5] - b[4]);
+        }
+        std::vector<double> sorted(extent);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const double median = sorted[n / 2];
+        std::vector<int> order(n);
+        for (int k = 0; k < n; k++) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return extent[a] > extent[b]; });
+        std::vector<char> direct(n, 0);
+        for (int q = 0; q < n && q < MAX_DIRECT; q++) {
+            int k = order[q];
+            if (!(extent[k] > 8.0 * median) && std::isfinite(extent[k])) break;
+            direct[k] = 1;
+        }
+        for (int k = 0; k < n; k++) {
+            if (!std::isfinite(extent[k])) direct[k] = 1;  // a box that is not finite cannot be sorted into a hierarchy
+            if (direct[k]) list_ids.push_back(k); else bvh_ids.push_back(k);
+        }
+    }
+    std::vector<DevGeom> list_geom(list_ids.size() ? list_ids.size() : 1);
+    for (size_t q = 0; q < list_ids.size(); q++) list_geom[q] = geom[list_ids[q]];
+    PtxBvhNode *d_bvh = nullptr;
+    int n_bvh_nodes = 0;
+    if (!bvh_ids.empty()) {
+        std::vector<double> boxes(6 * bvh_ids.size());
+        for (size_t q = 0; q < bvh_ids.size(); q++) memcpy(&boxes[6 * q], s->objects[bvh_ids[q]].box, 48);
+        std::string err;
+        if (ptx_bvh_build(boxes.data(), bvh_ids.data(), (int)bvh_ids.size(), c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
+            return fail(PTX_EDEVICE, "ptx_scene_upload: hierarchy build failed: " + err);
+    }
+    c->d_bvh = d_bvh;
+    c->use_bvh = n_bvh_nodes > 0;
+    HIPCHK(hipMalloc(&c->d_list_geom, list_geom.size() * sizeof(DevGeom)));
+    HIPCHK(hipMalloc(&c->d_list_ids, (list_ids.size() ? list_ids.size() : 1) * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(c->d_list_geom, list_geom.data(), list_geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
+    if (!list_ids.empty())
+        HIPCHK(hipMemcpy(c->d_list_ids, list_ids.data(), list_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->d_geom, geom.size() * sizeof(DevGeom)));
     HIPCHK(hipMalloc(&c->d_mat, mat.size() * sizeof(DevMat)));
     HIPCHK(hipMalloc(&c->d_lights, lights.size() * sizeof(DevLight)));
@@ -348,6 +404,11 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     d.lights = (const DevLight *)c->d_lights;
     d.images = (const DevImage *)c->d_images;
     d.texels = (const uint8_t *)c->d_texels;
+    d.list_geom = (const DevGeom *)c->d_list_geom;
+    d.list_ids = (const int32_t *)c->d_list_ids;
+    d.bvh = (const PtxBvhNode *)c->d_bvh;
+    d.n_list = (int32_t)list_ids.size();
+    d.n_bvh_nodes = n_bvh_nodes;
     d.n_objects = n; d.n_lights = s->n_lights; d.n_images = s->n_images; d.has_refraction = has_refr;
     const ptx_camera &cam = s->cam;
     for (int q = 0; q < 3; q++) { d.cam.e[q] = cam.e[q]; d.cam.w[q] = cam.w[q]; }
@@ -420,7 +481,7 @@ extern "C" int ptx_render_begin_external(ptx_context *c, const ptx_render_params
 }
 
 template <typename F>
-static void dispatch_flags(int flags, F &&f) {
+static void dispatch_flags_1(int flags, F &&f) {
     switch (flags & 7) {
     case 0: f(std::integral_constant<int, 0>()); break;
     case 1: f(std::integral_constant<int, 1>()); break;
@@ -433,6 +494,15 @@ static void dispatch_flags(int flags, F &&f) {
     }
 }
 
+// calls f(flags constant, hierarchy constant)
+template <typename F>
+static void dispatch_flags(int flags, bool use_bvh, F &&f) {
+    dispatch_flags_1(flags, [&](auto fl) {
+        if (use_bvh) f(fl, std::true_type());
+        else f(fl, std::false_type());
+    });
+}
+
 extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     if (!c) return fail(PTX_EINVAL, "null context");
     if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
@@ -443,9 +513,10 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     const long waves = (long)tiles_x * tiles_y;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    dispatch_flags(c->prm.flags, [&](auto fl) {
+    dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
         constexpr int F = decltype(fl)::value;
-        hipLaunchKernelGGL(k_render<F>, dim3(blocks), dim3(256), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
+        constexpr bool B = decltype(bv)::value;
+        hipLaunchKernelGGL((k_render<F, B>), dim3(blocks), dim3(256), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
                            c->d_wght, c->d_stats);
     });
     HIPCHK(hipGetLastError());
@@ -518,8 +589,12 @@ extern "C" int ptx_first_hit_device(ptx_context *c, const ptx_ray *d_rays, int64
     if (n < 0) return fail(PTX_EINVAL, "negative ray count");
     if (n == 0) return PTX_OK;
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_first_hit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays, (long)n,
-                       d_hits);
+    if (c->use_bvh)
+        hipLaunchKernelGGL(k_first_hit<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays,
+                           (long)n, d_hits);
+    else
+        hipLaunchKernelGGL(k_first_hit<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays,
+                           (long)n, d_hits);
     HIPCHK(hipGetLastError());
     return PTX_OK;
 }
@@ -578,9 +653,10 @@ extern "C" int ptx_trace_paths(ptx_context *c, const ptx_render_params *p, const
     (void)hipMemcpyAsync(d_idx, pi, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     (void)hipMemcpyAsync(d_idx + n, pj, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     (void)hipMemcpyAsync(d_idx + 2 * n, pk, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    dispatch_flags(p->flags, [&](auto fl) {
+    dispatch_flags(p->flags, c->use_bvh, [&](auto fl, auto bv) {
         constexpr int F = decltype(fl)::value;
-        hipLaunchKernelGGL(k_trace_paths<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, rp, d_idx,
+        constexpr bool B = decltype(bv)::value;
+        hipLaunchKernelGGL((k_trace_paths<F, B>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, rp, d_idx,
                            d_idx + n, d_idx + 2 * n, (long)n, d_out);
     });
     rc = PTX_OK;
