@@ -150,17 +150,33 @@ struct Rng {
 
 // --------------------------------------------------- per-lane LDS store
 // Cold per-lane state lives in LDS instead of registers: slot s of lane t is
-// word [s][t], so a wave touches 64 consecutive doubles (no bank conflicts)
+// word [s][t], so a wave touches 64 consecutive words (no bank conflicts)
 // and a lane can index its slots dynamically without going to scratch.
-//   slots 0..3   radiance accumulator r,g,b and weight of the lane's pixel
-//   slots 4..13  ray3D.r_index[0..9] (reference PathTracer.h:88)
-//   slots 14..16 ray3D.srcN x,y,z    (reference PathTracer.h:85)
-enum { LS_ACC = 0, LS_RINDEX = 4, LS_SRCN = 14, LS_SLOTS = 17 };
+// Double slots:
+//   0..3    radiance accumulator r,g,b and weight of the lane's pixel
+//   4..6    ray3D.srcN x,y,z (reference PathTracer.h:85)
+//   7..9    direction of the pixel's primary ray (the same for every sample when the aperture is zero: the
+//           reference samples pixel centres, PathTracer.c:625-628)
+//   10..18  colours of up to three finished paths waiting to be folded into the accumulator, in sample order
+// Int slots:
+//   0..9    ray3D.r_index[0..9] (reference PathTracer.h:88), held as the index of the object whose r_index
+//           was pushed (RI_ONE: the initial 1.0 of initRay; RI_ZERO: never written)
+// 19 double + 10 int slots = 48 KiB per 256-thread block, three blocks per CU.
+enum { LS_ACC = 0, LS_SRCN = 4, LS_PRIMARY_D = 7, LS_PENDING = 10, LS_PENDING_MAX = 3, LS_DSLOTS = LS_PENDING + 3 * LS_PENDING_MAX };
+enum { LS_RINDEX = 0, LS_ISLOTS = 10 };
+enum { RI_ONE = -1, RI_ZERO = -2 };
 struct LaneStore {
-    double *base;  // &lds[0][threadIdx.x]
+    double *base;  // &lds_d[0][threadIdx.x]
+    int *ibase;    // &lds_i[0][threadIdx.x]
     __device__ __forceinline__ double get(int slot) const { return base[slot * PTX_BLOCK]; }
     __device__ __forceinline__ void put(int slot, double v) const { base[slot * PTX_BLOCK] = v; }
+    __device__ __forceinline__ int geti(int slot) const { return ibase[slot * PTX_BLOCK]; }
+    __device__ __forceinline__ void puti(int slot, int v) const { ibase[slot * PTX_BLOCK] = v; }
 };
+#define PTX_LANE_STORE(ls)                                   \
+    __shared__ double lds_d_[LS_DSLOTS][PTX_BLOCK];          \
+    __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];             \
+    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]}
 
 // ------------------------------------------------------- transforms
 __device__ __forceinline__ V3 xform_point(const double *m, V3 p) {
@@ -182,13 +198,9 @@ __device__ __forceinline__ V3 xform_normal(const double *m, V3 n) {
 // (a value <= PT_TOL means "no usable hit") and, in `part`, which face or
 // section produced it.
 
-// Smallest root > TOL of the sphere quadratic, reference utils_path.c:564-587.
-__device__ __forceinline__ double sphere_roots(double l1, double l2) {
-    double lam = -1.0;
-    if (l1 > PT_TOL) lam = l1;
-    if (l2 > PT_TOL && (l1 <= PT_TOL || l2 < l1)) lam = l2;
-    return lam;
-}
+// Smallest root > TOL of the sphere quadratic (reference utils_path.c:564-587), given l2 <= l1: l2 if it
+// qualifies, else l1; the caller rejects a result that is not > TOL.
+__device__ __forceinline__ double sphere_roots(double l1, double l2) { return l2 > PT_TOL ? l2 : l1; }
 
 // sphereIntersect, reference utils_path.c:546-587, in object space
 __device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
@@ -580,8 +592,11 @@ struct Counters {
 // the out-of-range indices refractRay can produce (PathTracer.c:101, :131),
 // which land on neighbouring fields of struct ray3D: k=-1 srcN.pw (always 1),
 // -2..-4 srcN.pz..px, -5..-7 I.B..R, -8..-10 col.B..R, 10 = r_index_index.
-__device__ inline double rindex_load(Path &ps, const LaneStore &ls, int k, uint32_t &oob) {
-    if (k >= 0 && k <= 9) return ls.get(LS_RINDEX + k);
+__device__ inline double rindex_load(const DevScene &sc, Path &ps, const LaneStore &ls, int k, uint32_t &oob) {
+    if (k >= 0 && k <= 9) {
+        int id = ls.geti(LS_RINDEX + k);
+        return id >= 0 ? sc.mat[id].r_index : (id == RI_ONE ? 1.0 : 0.0);
+    }
     oob++;
     switch (k) {
     case -1: return 1.0;
@@ -598,9 +613,10 @@ __device__ inline double rindex_load(Path &ps, const LaneStore &ls, int k, uint3
     default: return 1.0;
     }
 }
-__device__ inline void rindex_store(Path &ps, const LaneStore &ls, int k, double v, uint32_t &oob) {
+// stores obj's r_index (value v) at r_index[k]
+__device__ inline void rindex_store(Path &ps, const LaneStore &ls, int k, int obj, double v, uint32_t &oob) {
     if (k >= 0 && k <= 9) {
-        ls.put(LS_RINDEX + k, v);
+        ls.puti(LS_RINDEX + k, obj);
         return;
     }
     oob++;
@@ -625,8 +641,9 @@ __device__ __forceinline__ V3 reflect_dir(V3 d, V3 n) {
 
 // refractRay, reference PathTracer.c:74-140.  n is normalised in place like
 // the reference's *normal.
-__device__ inline void refract_ray(Path &ps, const LaneStore &ls, V3 p, V3 &n, double obj_r_index, Counters &cnt) {
-    double n1 = rindex_load(ps, ls, ps.ridx, cnt.oob);
+__device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore &ls, V3 p, V3 &n, int obj, double obj_r_index,
+                                   Counters &cnt) {
+    double n1 = rindex_load(sc, ps, ls, ps.ridx, cnt.oob);
     double n2 = obj_r_index;
     double r = n1 / n2;
     bool leaving = false;
@@ -635,7 +652,7 @@ __device__ inline void refract_ray(Path &ps, const LaneStore &ls, V3 p, V3 &n, d
     V3 rn = n;
     if (!(dot3(ps.d, n) < 0)) {
         n1 = obj_r_index;
-        n2 = rindex_load(ps, ls, ps.ridx - 1, cnt.oob);
+        n2 = rindex_load(sc, ps, ls, ps.ridx - 1, cnt.oob);
         r = n1 / n2;
         rn = n * -1.0;
         leaving = true;
@@ -656,14 +673,33 @@ __device__ inline void refract_ray(Path &ps, const LaneStore &ls, V3 p, V3 &n, d
         ps.ridx = ps.ridx - 1;
     } else {
         ps.ridx = ps.ridx + 1;
-        rindex_store(ps, ls, ps.ridx, obj_r_index, cnt.oob);
+        rindex_store(ps, ls, ps.ridx, obj, obj_r_index, cnt.oob);
     }
     ps.d = norm3(ps.d * r + rn * (r * c - sqrt(disc)));
 }
 
+// Everything of a new path except its ray: initRay (reference utils_path.h:211-230) and PathTrace's initial
+// arguments (PathTracer.c:644).
+__device__ __forceinline__ void path_init(const DevScene &sc, const LaneStore &ls, Path &ps) {
+    ps.col = mk(1, 1, 1);
+    ps.I = mk(0, 0, 0);
+    ps.os = -1;
+    ps.cel = 0;
+    ps.depth = 1;
+    ps.ridx = 0;
+    if (sc.has_refraction) {
+        ls.puti(LS_RINDEX + 0, RI_ONE);
+#pragma unroll
+        for (int q = 1; q < 10; q++) ls.puti(LS_RINDEX + q, RI_ZERO);
+        ls.put(LS_SRCN + 0, 0.0);
+        ls.put(LS_SRCN + 1, 0.0);
+        ls.put(LS_SRCN + 2, 1.0);
+    }
+}
+
 // Primary ray of pixel (i,j), sample k: reference PathTracer.c:625-641 with
-// sampleLensPoint (:142-158), focusRay (:160-195), initRay
-// (utils_path.h:211-230).  Two draws are consumed whatever the aperture.
+// sampleLensPoint (:142-158) and focusRay (:160-195).  Two draws are consumed
+// whatever the aperture; with a zero aperture they do not enter the result.
 __device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, const LaneStore &ls, int i, int j, int k,
                                    Path &ps) {
     ps.rng.ctr = ptx_path_key(rp.seed, (uint64_t)j * (uint64_t)rp.sx + (uint64_t)i, (uint64_t)k);
@@ -689,20 +725,18 @@ __device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, cons
     V3 hit = pc + rayd * lambda;
     ps.p0 = pl;
     ps.d = norm3(hit - pl);
-    ps.col = mk(1, 1, 1);
-    ps.I = mk(0, 0, 0);
-    ps.os = -1;
-    ps.cel = 0;
-    ps.depth = 1;
-    ps.ridx = 0;
-    if (sc.has_refraction) {
-        ls.put(LS_RINDEX + 0, 1.0);
-#pragma unroll
-        for (int q = 1; q < 10; q++) ls.put(LS_RINDEX + q, 0.0);
-        ls.put(LS_SRCN + 0, 0.0);
-        ls.put(LS_SRCN + 1, 0.0);
-        ls.put(LS_SRCN + 2, 1.0);
-    }
+    path_init(sc, ls, ps);
+}
+
+// The same when the direction has been computed before and parked in the lane's LDS slots (zero aperture only).
+__device__ __forceinline__ void primary_ray_cached(const DevScene &sc, const DevRender &rp, const LaneStore &ls, int i, int j,
+                                                   int k, Path &ps) {
+    ps.rng.ctr = ptx_path_key(rp.seed, (uint64_t)j * (uint64_t)rp.sx + (uint64_t)i, (uint64_t)k);
+    ps.rng.skip(2);
+    const DevCamera &cam = sc.cam;
+    ps.p0 = xform_point(cam.C2W, mk(cam.wl + (i * rp.du), cam.wt + (j * rp.dv), cam.f));
+    ps.d = mk(ls.get(LS_PRIMARY_D + 0), ls.get(LS_PRIMARY_D + 1), ls.get(LS_PRIMARY_D + 2));
+    path_init(sc, ls, ps);
 }
 
 // Light-point samplers: planeSample / sphereSample (reference
@@ -826,7 +860,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         }
     } else if (dice <= diffusivity + reflectivity + transparency) {
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        refract_ray(ps, ls, p, n, mt.r_index, cnt);
+        refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
         next_os = -1;
     }
     if (sc.has_refraction) {

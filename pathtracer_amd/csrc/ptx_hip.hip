@@ -33,8 +33,7 @@ template <int FLAGS, bool USE_BVH>
 __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
              unsigned long long *__restrict__ stats) {
-    __shared__ double lds[LS_SLOTS][PTX_BLOCK];
-    const LaneStore ls{&lds[0][threadIdx.x]};
+    PTX_LANE_STORE(ls);
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (PTX_BLOCK >> 6) + (threadIdx.x >> 6);
     const int tiles_x = (rp.sx + 7) >> 3;
@@ -56,27 +55,52 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     Path ps;
     bool alive = false;
     int k = inside ? k0 : k1;
+    const bool cache_primary = rp.aperture == 0;
+    if (cache_primary && inside) {
+        primary_ray(sc, rp, ls, i, j, k0, ps);
+        ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
+    }
+    // Finished paths are folded into the accumulator in batches: a lane parks the colour of each finished path
+    // (at most LS_PENDING_MAX of them), and when any lane of the wave has filled its slots every lane folds what it
+    // has, in sample order.  The fold (a log and an exp2 per sample) then runs with most lanes active instead of
+    // the quarter that finish in any one iteration.
+    int pending = 0;
     for (;;) {
         bool ended = false;
         if (!alive && k < k1) {
-            primary_ray(sc, rp, ls, i, j, k, ps);
+            if (cache_primary) primary_ray_cached(sc, rp, ls, i, j, k, ps);
+            else primary_ray(sc, rp, ls, i, j, k, ps);
             alive = true;
             ended = rp.max_depth < 1;  // reference PathTracer.c:273 with depth = 1
         }
-        if (__ballot(alive) == 0ULL) break;
+        const bool any_alive = __ballot(alive) != 0ULL;
+        if (!any_alive || __ballot(pending == LS_PENDING_MAX) != 0ULL) {
+            // fold, reference PathTracer.c:646-652
+            if (pending > 0) {
+                double ar = ls.get(LS_ACC + 0), ag = ls.get(LS_ACC + 1), ab = ls.get(LS_ACC + 2), wt = ls.get(LS_ACC + 3);
+                for (int q = 0; q < pending; q++) {
+                    double cr = ls.get(LS_PENDING + 3 * q), cg = ls.get(LS_PENDING + 3 * q + 1),
+                           cb = ls.get(LS_PENDING + 3 * q + 2);
+                    double f = exp2(-log(wt));
+                    ar += cr * f;
+                    ag += cg * f;
+                    ab += cb * f;
+                    wt += cr;
+                    wt += cg;
+                    wt += cb;
+                }
+                ls.put(LS_ACC + 0, ar); ls.put(LS_ACC + 1, ag); ls.put(LS_ACC + 2, ab); ls.put(LS_ACC + 3, wt);
+                pending = 0;
+            }
+        }
+        if (!any_alive) break;
         if (alive) {
             if (!ended) ended = bounce<FLAGS, USE_BVH>(sc, rp, ls, ps, cnt);
             if (ended) {
-                // fold, reference PathTracer.c:646-652
-                double wt = ls.get(LS_ACC + 3);
-                double f = exp2(-log(wt));
-                ls.put(LS_ACC + 0, ls.get(LS_ACC + 0) + ps.I.x * f);
-                ls.put(LS_ACC + 1, ls.get(LS_ACC + 1) + ps.I.y * f);
-                ls.put(LS_ACC + 2, ls.get(LS_ACC + 2) + ps.I.z * f);
-                wt += ps.I.x;
-                wt += ps.I.y;
-                wt += ps.I.z;
-                ls.put(LS_ACC + 3, wt);
+                ls.put(LS_PENDING + 3 * pending, ps.I.x);
+                ls.put(LS_PENDING + 3 * pending + 1, ps.I.y);
+                ls.put(LS_PENDING + 3 * pending + 2, ps.I.z);
+                pending++;
                 alive = false;
                 k++;
                 paths++;
@@ -109,8 +133,7 @@ template <int FLAGS, bool USE_BVH>
 __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
                                                             const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
                                                             long n, double *__restrict__ out) {
-    __shared__ double lds[LS_SLOTS][PTX_BLOCK];
-    const LaneStore ls{&lds[0][threadIdx.x]};
+    PTX_LANE_STORE(ls);
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     Counters cnt = {0, 0, 0};
