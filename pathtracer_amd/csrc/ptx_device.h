@@ -57,6 +57,14 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     g = fma(d, h, g);
     return x > 0.0 ? g : 0.0;
 }
+// 1/sqrt(x) for finite x > 0: hardware estimate plus two coupled Newton steps (error about 1 ulp)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * e, fma(0.375, e, 0.5), y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
     return v * rsqrt(dot3(v, v));
 }
@@ -68,14 +76,17 @@ __device__ __forceinline__ double comp(V3 v, int a) { return a == 0 ? v.x : (a =
 //   analytic primitives: m[0..11] = rows 0..2 of Tinv (3x4)
 //   triangles:           m[0..8]  = v1 v2 v3 (world space), m[9..11] = unit normal
 //   fast = 1: a sphere whose transform is a uniform scale plus a translation;
-//             c = centre, r2 = radius^2, inv_r = 1/radius
+//             c = centre, e[0] = radius^2, e[1] = 1/radius
+//   planes:   c = world-space unit normal for a ray that starts on the canonical +z side, e = the same for the
+//             -z side (normalTransform of (0,0,1) and (0,0,-1); they differ in more than sign where a component
+//             is a signed zero, which the sampling rotation tells apart)
 struct DevGeom {
     int32_t type;
     int32_t fast;
     double m[12];
     double c[3];
-    double r2, inv_r;
-    double pad[2];
+    double e[3];
+    double pad;
 };
 static_assert(sizeof(DevGeom) == 160, "DevGeom layout");
 
@@ -219,7 +230,7 @@ __device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
 // by all spheres of one ray.
 __device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, V3 d, double dd, double inv_dd) {
     V3 oc = mk(p0.x - g.c[0], p0.y - g.c[1], p0.z - g.c[2]);
-    double B = dot3(oc, d), C = dot3(oc, oc) - g.r2;
+    double B = dot3(oc, d), C = dot3(oc, oc) - g.e[0];
     double disc = B * B - dd * C;
     if (disc < 0.0) return -1.0;
     double sq = fast_sqrt(disc);
@@ -403,12 +414,19 @@ __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 
     }
     if (g.fast) {
         // canonical point (p-c)/r; Tinv^T is a multiple of the identity, so the normal is its direction
-        V3 pc = mk(p.x - g.c[0], p.y - g.c[1], p.z - g.c[2]) * g.inv_r;
+        V3 pc = mk(p.x - g.c[0], p.y - g.c[1], p.z - g.c[2]) * g.e[1];
         n = norm3(pc);
         if (WANT_UV) {
             a = atan2(pc.y, pc.x) / (2 * PT_PI);
             b = acos(pc.z) / PT_PI;
         }
+        return;
+    }
+    if (!WANT_UV && type == PTX_PLANE) {
+        // planeIntersect picks the side the ray starts on (reference utils_path.c:505-519)
+        double tz = g.m[8] * p0.x + g.m[9] * p0.y + g.m[10] * p0.z + g.m[11];
+        const double *nn = tz < 0 ? g.e : g.c;
+        n = mk(nn[0], nn[1], nn[2]);
         return;
     }
     double m[12];
@@ -508,16 +526,18 @@ __device__ __forceinline__ double alpha_map(const DevScene &sc, int img, double 
 // sines and cosines of those angles are taken from n directly.
 __device__ __forceinline__ V3 rotate_z_to(V3 n, V3 v) {
     double h2 = n.x * n.x + n.y * n.y;
-    double ct = 1.0, st = 0.0;  // atan2(0,0) = 0
+    double ct = 1.0, st = 0.0, sp = 0.0;  // atan2(0,0) = 0
     if (h2 > 0) {
-        double ih = rsqrt(h2);
+        double ih = fast_rsqrt(h2);
         ct = n.x * ih;
         st = n.y * ih;
+        sp = h2 * ih;  // sin(acos(n.z)) of a unit vector
     } else if (n.x < 0 || (n.x == 0 && signbit(n.x))) {
         ct = -1.0;  // atan2(+-0, -0) = +-pi
     }
-    double cp = n.z > 1.0 ? NAN : (n.z < -1.0 ? NAN : n.z);  // acos outside [-1,1] is NaN in the reference
-    double sp = sqrt(fmax(0.0, 1.0 - cp * cp));
+    // cos(acos(n.z)): a unit vector whose z exceeds 1 by a rounding error (where the reference's acos would
+    // give NaN) is taken as it is
+    const double cp = n.z;
     double x1 = v.x * cp + v.z * sp;
     double z1 = -v.x * sp + v.z * cp;
     return mk(x1 * ct - v.y * st, x1 * st + v.y * ct, z1);
@@ -537,12 +557,12 @@ __device__ __forceinline__ void sincos_turn(double u, double &s, double &c) { si
 // cosWeightedSample, reference utils_path.c:1224-1265 (two draws)
 __device__ __forceinline__ V3 cos_weighted_sample(V3 n, Rng &rng) {
     double u1 = rng.next();
-    double r = sqrt(u1);
+    double r = fast_sqrt(u1);
     double u2 = rng.next();
     double s, c;
     sincos_turn(u2, s, c);
     double x = r * c, y = r * s;
-    double z = sqrt(1.0 - x * x - y * y);
+    double z = fast_sqrt(1.0 - x * x - y * y);
     return rotate_z_to(n, mk(x, y, z));
 }
 
@@ -645,7 +665,6 @@ __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore
                                    Counters &cnt) {
     double n1 = rindex_load(sc, ps, ls, ps.ridx, cnt.oob);
     double n2 = obj_r_index;
-    double r = n1 / n2;
     bool leaving = false;
     ps.d = norm3(ps.d);
     n = norm3(n);
@@ -653,10 +672,10 @@ __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore
     if (!(dot3(ps.d, n) < 0)) {
         n1 = obj_r_index;
         n2 = rindex_load(sc, ps, ls, ps.ridx - 1, cnt.oob);
-        r = n1 / n2;
         rn = n * -1.0;
         leaving = true;
     }
+    const double r = n1 / n2;
     double c = -dot3(rn, ps.d);
     double disc = 1 - (r * r) * (1 - (c * c));
     double q = (n1 - n2) / (n1 + n2);
@@ -765,8 +784,12 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
 // ended, its colour then being ps.I.  The reference's depth test at the top
 // of the next invocation (:273) is applied at the end of this one, so a path
 // that has used up its depth ends without another trip through the loop.
-template <int FLAGS, bool USE_BVH>
-__device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt) {
+// With DEFER_GLOSSY the three normal deviates of a glossy mirror bounce (:460-464) are not drawn here: the
+// lane reports its refl_sig in `glossy` (0 otherwise) and the caller adds them with glossy_service().
+template <int FLAGS, bool USE_BVH, bool DEFER_GLOSSY>
+__device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt,
+                              double &glossy) {
+    glossy = 0;
     ps.d = norm3(ps.d);
     cnt.closest++;
     Hit h = closest_hit_all<USE_BVH>(sc, ps.p0, ps.d, ps.os);
@@ -854,9 +877,13 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         ps.p0 = p;
         const double sig = mt.refl_sig;
         if (sig > 0) {
-            ps.d.x += sig * random_normal(ps.rng);
-            ps.d.y += sig * random_normal(ps.rng);
-            ps.d.z += sig * random_normal(ps.rng);
+            if (DEFER_GLOSSY) {
+                glossy = sig;
+            } else {
+                ps.d.x += sig * random_normal(ps.rng);
+                ps.d.y += sig * random_normal(ps.rng);
+                ps.d.z += sig * random_normal(ps.rng);
+            }
         }
     } else if (dice <= diffusivity + reflectivity + transparency) {
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
@@ -871,4 +898,40 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     ps.os = next_os;
     ps.depth++;
     return ps.depth > rp.max_depth;
+}
+
+// The glossy perturbation d += refl_sig * (N1, N2, N3) (reference PathTracer.c:460-464) for every lane of the
+// wave that asked for it, to be called by all 64 lanes together.  Few lanes reflect off a glossy surface in any
+// one bounce, and each needs three independent deviates (a log, a cos and a square root apiece), so the deviates
+// are handed out to the lanes of the wave, one per lane, and sent back with lane permutes: lane 3q+c computes
+// deviate c of the q-th requesting lane from that lane's counter, which gives the bits the lane itself would get.
+__device__ __forceinline__ void glossy_service(Path &ps, double glossy, int lane) {
+    const unsigned long long req = __ballot(glossy > 0);
+    if (req == 0ULL) return;
+    const int n_req = __popcll(req);
+    const int rank = __popcll(req & ((1ULL << lane) - 1ULL));
+    for (int base = 0; base < n_req; base += 21) {
+        const int q = base + lane / 3, c = lane - 3 * (lane / 3);
+        const bool work = lane < 63 && q < n_req;
+        unsigned long long m = req;
+        for (int t = 0; t < q && work; t++) m &= m - 1;  // drop the q lowest requesters
+        const int src = work ? __ffsll((long long)m) - 1 : lane;
+        const unsigned long long ctr = __shfl(ps.rng.ctr, src);
+        double dev = 0;
+        if (work) {
+            Rng r;
+            r.ctr = ctr + PTX_GOLDEN * (unsigned long long)(2 * c);
+            dev = random_normal(r);
+        }
+        const int mine = rank - base;
+        const bool served = glossy > 0 && mine >= 0 && mine < 21;
+        const int from = served ? 3 * mine : 0;
+        double n0 = __shfl(dev, from), n1 = __shfl(dev, from + 1), n2 = __shfl(dev, from + 2);
+        if (served) {
+            ps.d.x += glossy * n0;
+            ps.d.y += glossy * n1;
+            ps.d.z += glossy * n2;
+            ps.rng.skip(6);
+        }
+    }
 }

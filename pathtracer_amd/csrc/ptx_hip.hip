@@ -94,8 +94,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
             }
         }
         if (!any_alive) break;
+        double glossy = 0;
+        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true>(sc, rp, ls, ps, cnt, glossy);
+        glossy_service(ps, glossy, lane);
         if (alive) {
-            if (!ended) ended = bounce<FLAGS, USE_BVH>(sc, rp, ls, ps, cnt);
             if (ended) {
                 ls.put(LS_PENDING + 3 * pending, ps.I.x);
                 ls.put(LS_PENDING + 3 * pending + 1, ps.I.y);
@@ -140,7 +142,8 @@ __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRende
     Path ps;
     primary_ray(sc, rp, ls, pi[q], pj[q], pk[q], ps);
     if (rp.max_depth >= 1) {
-        while (!bounce<FLAGS, USE_BVH>(sc, rp, ls, ps, cnt)) {
+        double glossy;
+        while (!bounce<FLAGS, USE_BVH, false>(sc, rp, ls, ps, cnt, glossy)) {
         }
     }
     out[3 * q + 0] = ps.I.x;
@@ -328,8 +331,18 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
             if (o.type == PTX_SPHERE && diag && T[0] > 0 && T[0] == T[5] && T[0] == T[10]) {
                 g.fast = 1;
                 g.c[0] = T[3]; g.c[1] = T[7]; g.c[2] = T[11];
-                g.r2 = T[0] * T[0];
-                g.inv_r = 1.0 / T[0];
+                g.e[0] = T[0] * T[0];
+                g.e[1] = 1.0 / T[0];
+            }
+            if (o.type == PTX_PLANE) {
+                // normalTransform (reference utils_path.c:58-76) of the two canonical normals, term by term
+                for (int side = 0; side < 2; side++) {
+                    const double nz = side ? -1.0 : 1.0;
+                    double v[3];
+                    for (int q = 0; q < 3; q++) v[q] = g.m[q] * 0.0 + g.m[4 + q] * 0.0 + g.m[8 + q] * nz;
+                    double l = 1.0 / sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    for (int q = 0; q < 3; q++) (side ? g.e : g.c)[q] = v[q] * l;
+                }
             }
         }
         DevMat &m = mat[k];

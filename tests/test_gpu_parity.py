@@ -22,9 +22,9 @@ ALL = pt.abi.USE_IS | pt.abi.USE_ES | pt.abi.USE_RR
 # ulp of a threshold, or chaotic amplification through refraction.  Measured: < 0.2 % away from exact ties.
 MAX_PATH_MISMATCH = 0.004
 # SciFiCube is a sponge of cubes with exactly coincident faces: a ray through a shared face meets two surfaces at
-# the same distance and rounding picks one, in the reference as much as here, so a few percent of its paths differ
-# between any two implementations that do not share every rounding.
-MAX_PATH_MISMATCH_BY_SCENE = {"scifi": 0.03}
+# the same distance and rounding picks one, in the reference as much as here, so more of its paths differ
+# between two implementations that do not share every rounding.  Measured: 0.3 %.
+MAX_PATH_MISMATCH_BY_SCENE = {"scifi": 0.01}
 
 
 @pytest.mark.parametrize("name", ["cornell", "prims", "scifi", "bubbletea"])
