@@ -22,6 +22,26 @@ FLOP_PER_PATH = 3.9e3
 PEAK_FP32_TFLOPS = 157.3
 
 
+def recorded_hbm_traffic(rows, sx):
+    """HBM bytes of one render launch from the newest counter summary under profiles/ (written by
+    tools/collect_profiles.sh: FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE).  The counters cannot be read
+    from inside this process, so the figure is the recorded one, scaled to this rank's share of the pixels (the
+    traffic is the accumulators, read once and written once per launch whatever the sample count)."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path))
+        except (OSError, ValueError, KeyError):
+            continue
+    if best is None:
+        return None, None
+    return best[0] * (rows * sx) / float(1024 * 1024), best[1]
+
+
 def cpu_baseline(sx, depth, flags, seconds_target=15.0):
     """Times the CPU side on a bounded sample of the same workload: the compiled reference if it was built
     (oracle/_ref), else the CPU oracle."""
@@ -160,6 +180,7 @@ def main():
     paths_launches = sum(rows * sx * nk for _, nk in kernel_ms)
     achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
     rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
+    traffic, traffic_src = recorded_hbm_traffic(rows, sx) if sx == 1024 else (None, None)
     out = {
         "metric": "paths/s (pixel-samples per second), Cornell box 1024^2 depth 6 IS+ES+RR",
         "value": paths_per_s,
@@ -187,7 +208,9 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_hbm_bytes_per_launch": 64 * rows * sx,
             "kernel": "k_render",
             "kernel_ms_avg": ms_sum / max(1, len(kernel_ms)),
             "flop_per_path_model": FLOP_PER_PATH,
