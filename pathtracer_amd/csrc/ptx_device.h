@@ -24,7 +24,9 @@
 // 2*PT_PI/pi rounded to binary64: sin(2*PT_PI*u) = sinpi(PT_TWO_PI_OVER_PI*u)
 #define PT_TWO_PI_OVER_PI 0x1.ffffffffdd257p+0
 
-#define PTX_BLOCK 256  // threads per workgroup of every kernel that uses LaneStore
+// Threads per workgroup of every kernel that uses LaneStore: one wave.  A workgroup's place on its compute unit
+// is free again only when all its waves are done, and waves of the render kernel run for different times.
+#define PTX_BLOCK 64
 
 struct V3 {
     double x, y, z;
@@ -46,27 +48,26 @@ __device__ __forceinline__ double fast_rcp(double x) {
     e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
-// sqrt(x) for x >= 0 (0 for x == 0), from the hardware reciprocal square root plus Goldschmidt steps.
+// sqrt(x) for x >= 0, from the hardware reciprocal square root plus Goldschmidt steps.  Arguments below 1e-300
+// (zero, and the negative rounding residue of an expression that is zero in exact arithmetic) give 1e-150.
 __device__ __forceinline__ double fast_sqrt(double x) {
+    x = fmax(x, 1e-300);
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return x > 0.0 ? g : 0.0;
+    return fma(d, h, g);
 }
-// 1/sqrt(x) for finite x > 0: hardware estimate plus two coupled Newton steps (error about 1 ulp)
+// 1/sqrt(x) for finite x > 0: hardware estimate plus one third-order correction (error about 1 ulp)
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
     double e = fma(-x * y, y, 1.0);
-    y = fma(y * e, fma(0.375, e, 0.5), y);
-    e = fma(-x * y, y, 1.0);
-    return fma(0.5 * y, e, y);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
-    return v * rsqrt(dot3(v, v));
+    return v * fast_rsqrt(dot3(v, v));
 }
 __device__ __forceinline__ double comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
@@ -172,7 +173,7 @@ struct Rng {
 // Int slots:
 //   0..9    ray3D.r_index[0..9] (reference PathTracer.h:88), held as the index of the object whose r_index
 //           was pushed (RI_ONE: the initial 1.0 of initRay; RI_ZERO: never written)
-// 19 double + 10 int slots = 48 KiB per 256-thread block, three blocks per CU.
+// 19 double + 10 int slots = 12 KiB per wave, twelve waves per CU.
 enum { LS_ACC = 0, LS_SRCN = 4, LS_PRIMARY_D = 7, LS_PENDING = 10, LS_PENDING_MAX = 3, LS_DSLOTS = LS_PENDING + 3 * LS_PENDING_MAX };
 enum { LS_RINDEX = 0, LS_ISLOTS = 10 };
 enum { RI_ONE = -1, RI_ZERO = -2 };
@@ -234,7 +235,9 @@ __device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, 
     double disc = B * B - dd * C;
     if (disc < 0.0) return -1.0;
     double sq = fast_sqrt(disc);
-    return sphere_roots((sq - B) * inv_dd, (-B - sq) * inv_dd);
+    // the smaller root if it exceeds TOL, else the larger (sphere_roots), chosen before the division by d.d
+    double t2 = -B - sq;
+    return (t2 > PT_TOL * dd ? t2 : sq - B) * inv_dd;
 }
 
 // planeIntersect + planeHelper, reference utils_path.c:439-544
@@ -849,7 +852,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             V3 lp = light_sample(sc.lights[li], ps.rng);
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
-            V3 ed = dl * rsqrt(d2);
+            V3 ed = dl * fast_rsqrt(d2);
             cnt.shadow++;
             Hit sh = closest_hit_all<USE_BVH>(sc, p, ed, h.obj);
             int lit = 0;

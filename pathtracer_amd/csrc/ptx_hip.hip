@@ -547,12 +547,13 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     HIPCHK(hipSetDevice(c->device));
     const int tiles_x = (c->rp.sx + 7) / 8, tiles_y = (c->rp.rows_owned + 7) / 8;
     const long waves = (long)tiles_x * tiles_y;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const long waves_per_block = PTX_BLOCK / 64;
+    const unsigned blocks = (unsigned)((waves + waves_per_block - 1) / waves_per_block);
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
         constexpr int F = decltype(fl)::value;
         constexpr bool B = decltype(bv)::value;
-        hipLaunchKernelGGL((k_render<F, B>), dim3(blocks), dim3(256), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
+        hipLaunchKernelGGL((k_render<F, B>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
                            c->d_wght, c->d_stats);
     });
     HIPCHK(hipGetLastError());
@@ -692,7 +693,7 @@ extern "C" int ptx_trace_paths(ptx_context *c, const ptx_render_params *p, const
     dispatch_flags(p->flags, c->use_bvh, [&](auto fl, auto bv) {
         constexpr int F = decltype(fl)::value;
         constexpr bool B = decltype(bv)::value;
-        hipLaunchKernelGGL((k_trace_paths<F, B>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, rp, d_idx,
+        hipLaunchKernelGGL((k_trace_paths<F, B>), dim3((unsigned)((n + PTX_BLOCK - 1) / PTX_BLOCK)), dim3(PTX_BLOCK), 0, c->stream, c->sc, rp, d_idx,
                            d_idx + n, d_idx + 2 * n, (long)n, d_out);
     });
     rc = PTX_OK;
