@@ -89,6 +89,23 @@ int ptx_sync(ptx_context *ctx);
  * dataOutput() (PathTracer.c:655, :661). */
 int ptx_download(ptx_context *ctx, double *rgbIm, double *wght);
 
+/* What dataOutput() prints and chooses while tone mapping (reference utils_path.c:2011-2047): the minimum and
+ * maximum of the accumulator values, and the low and high cut picked from the 1000-bin histogram. */
+typedef struct ptx_tonemap_info {
+    double min, max;
+    double low_cut, high_cut;
+    uint64_t recomputed_on_host; /* values whose byte depended on the last bit of pow(): redone with libm */
+} ptx_tonemap_info;
+
+/* The tone mapping of dataOutput() (reference utils_path.c:2011-2060: normalise by the global minimum and
+ * maximum, 1000-bin histogram, cut selection, clip, power 0.75, bytes) of this context's radiance accumulator,
+ * which must hold the whole image (one rank).  bits receives sx*sx*3 bytes, the payload of the reference's P6
+ * file, identical to what dataOutput() computes from the same accumulator.  info may be NULL. */
+int ptx_tonemap(ptx_context *ctx, uint8_t *bits, ptx_tonemap_info *info);
+
+/* The same for any device buffer of n_values doubles (an image gathered from several ranks, for instance). */
+int ptx_tonemap_device(ptx_context *ctx, const double *d_im, uint64_t n_values, uint8_t *bits, ptx_tonemap_info *info);
+
 /* Device addresses of this rank's accumulators and the number of rows they
  * hold (for a device-side gather).  */
 int ptx_accumulators(ptx_context *ctx, double **d_rgb, double **d_wght, int32_t *rows_owned);

@@ -23,6 +23,7 @@
 
 #include "ptx_device.h"
 #include "ptx_hip.h"
+#include "ptx_internal.h"
 
 #ifndef PTX_RENDER_WAVES_PER_EU
 #define PTX_RENDER_WAVES_PER_EU 3
@@ -575,6 +576,22 @@ extern "C" int ptx_last_pass_ms(ptx_context *c, float *ms) {
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return PTX_OK;
+}
+
+extern "C" int ptx_tonemap_device(ptx_context *c, const double *d_im, uint64_t n_values, uint8_t *bits, ptx_tonemap_info *info) {
+    if (!c || !d_im || !bits) return fail(PTX_EINVAL, "ptx_tonemap_device: null argument");
+    if (n_values == 0) return fail(PTX_EINVAL, "ptx_tonemap_device: empty image");
+    HIPCHK(hipSetDevice(c->device));
+    std::string err;
+    int rc = ptx_tonemap_run(c->stream, d_im, (size_t)n_values, bits, info, err);
+    return rc ? fail(rc, err) : PTX_OK;
+}
+
+extern "C" int ptx_tonemap(ptx_context *c, uint8_t *bits, ptx_tonemap_info *info) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    if (c->rp.rows_owned != c->rp.sx) return fail(PTX_ESTATE, "ptx_tonemap: this rank holds only part of the image");
+    return ptx_tonemap_device(c, c->d_rgb, (uint64_t)c->rp.sx * c->rp.sx * 3, bits, info);
 }
 
 extern "C" int ptx_accumulators(ptx_context *c, double **d_rgb, double **d_wght, int32_t *rows) {

@@ -18,6 +18,7 @@ EXPORTS = [
     "ptx_init", "ptx_shutdown", "ptx_scene_upload", "ptx_render_begin", "ptx_render_begin_external",
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
+    "ptx_tonemap", "ptx_tonemap_device",
 ]
 
 
@@ -53,6 +54,8 @@ def load_library(path=None):
     lib.ptx_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     lib.ptx_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ptx_set_stream.argtypes = [vp, vp]
+    lib.ptx_tonemap.argtypes = [vp, vp, C.POINTER(abi.TonemapInfo)]
+    lib.ptx_tonemap_device.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(abi.TonemapInfo)]
     lib.ptx_last_error.restype = C.c_char_p
     lib.ptx_version.restype = C.c_char_p
     if path is None:
@@ -136,6 +139,20 @@ class Device:
         self._check(self.lib.ptx_trace_paths(self.ctx, C.byref(params), pi.ctypes.data, pj.ctypes.data, pk.ctypes.data,
                                              len(pi), out.ctypes.data))
         return out
+
+    def tonemap(self, d_im=None, n_values=None):
+        """Bytes of the reference's P6 output for this context's accumulator (or for a device buffer of n_values
+        doubles) and what dataOutput() reports while making them."""
+        info = abi.TonemapInfo()
+        if d_im is None:
+            n_values = self.params.sx * self.params.sx * 3
+            bits = np.zeros(n_values, dtype=np.uint8)
+            self._check(self.lib.ptx_tonemap(self.ctx, bits.ctypes.data, C.byref(info)))
+        else:
+            bits = np.zeros(n_values, dtype=np.uint8)
+            self._check(self.lib.ptx_tonemap_device(self.ctx, d_im, n_values, bits.ctypes.data, C.byref(info)))
+        return bits, {"min": info.min, "max": info.max, "low_cut": info.low_cut, "high_cut": info.high_cut,
+                      "recomputed_on_host": info.recomputed_on_host}
 
     def stats(self):
         s = abi.Stats()

@@ -169,6 +169,8 @@ struct image *readPGMimage(const char *filename);
 struct image *newImage(int size_x, int size_y);
 void deleteImage(struct image *im);
 void dataOutput(double *im, int sx, char *name);
+void ptxh_write_output(const double *im, const unsigned char *bits, int sx, const char *name, double mi, double mx,
+                       double low_cut, double high_cut);
 void cleanup(struct object3D *o_list, struct textureNode *t_list);
 
 /* ---- what sits between buildScene() and the GPU library */

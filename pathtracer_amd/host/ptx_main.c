@@ -25,6 +25,19 @@ static int die_gpu(const char *what) {
     exit(0);
 }
 
+/* dataOutput() (reference PathTracer.c:655, :661) with the tone mapping done on the GPU: same two files, same
+ * bytes, same messages.  PTX_HOST_TONEMAP=1 in the environment runs the host routine instead. */
+static void output_image(ptx_context *gpu, double *rgbIm, double *wght, unsigned char *bits, int sx, char *name) {
+    if (ptx_download(gpu, rgbIm, wght) != 0) die_gpu("ptx_download");
+    if (getenv("PTX_HOST_TONEMAP")) {
+        dataOutput(rgbIm, sx, name);
+        return;
+    }
+    ptx_tonemap_info info;
+    if (ptx_tonemap(gpu, bits, &info) != 0) die_gpu("ptx_tonemap");
+    ptxh_write_output(rgbIm, bits, sx, name, info.min, info.max, info.low_cut, info.high_cut);
+}
+
 int main(int argc, char *argv[]) {
     if (argc < 5) {
         fprintf(stderr, "PathTracer: Can not parse input parameters\n");
@@ -65,7 +78,8 @@ int main(int argc, char *argv[]) {
 
     struct image *im = newImage(sx, sx);
     double *wght = (double *)calloc((size_t)sx * sx, sizeof(double));
-    if (!im || !wght) {
+    unsigned char *bits = (unsigned char *)malloc((size_t)sx * sx * 3);
+    if (!im || !wght || !bits) {
         fprintf(stderr, "Unable to allocate memory for image\n");
         exit(0);
     }
@@ -123,16 +137,12 @@ int main(int argc, char *argv[]) {
         for (int q = k; q < upto; q++) fprintf(stderr, "%d/%d, ", q, num_samples);
         if (ptx_render_passes(gpu, k, upto - k) != 0) die_gpu("ptx_render_passes");
         k = upto;
-        if ((k - 1) % 25 == 0) {
-            if (ptx_download(gpu, rgbIm, wght) != 0) die_gpu("ptx_download");
-            dataOutput(rgbIm, sx, output_name);
-        }
+        if ((k - 1) % 25 == 0) output_image(gpu, rgbIm, wght, bits, sx, output_name);
     }
     if (ptx_sync(gpu) != 0) die_gpu("ptx_sync");
     clock_gettime(CLOCK_MONOTONIC, &t2);
     fprintf(stderr, "\nDone!\n");
-    if (ptx_download(gpu, rgbIm, wght) != 0) die_gpu("ptx_download");
-    dataOutput(rgbIm, sx, output_name);
+    output_image(gpu, rgbIm, wght, bits, sx, output_name);
 
     ptx_stats st;
     if (ptx_get_stats(gpu, &st) != 0) die_gpu("ptx_get_stats");
@@ -147,5 +157,6 @@ int main(int argc, char *argv[]) {
     ptxh_reset();
     deleteImage(im);
     free(wght);
+    free(bits);
     exit(0);
 }

@@ -6,6 +6,31 @@
  */
 #include "ptx_kit.h"
 
+/* The two files of dataOutput() from an accumulator and bytes that were tone-mapped elsewhere (on the GPU, by
+ * ptx_tonemap): <name>.pfm and <name>, with the two lines the reference prints in between. */
+void ptxh_write_output(const double *im, const unsigned char *bits, int sx, const char *name, double mi, double mx,
+                       double low_cut, double high_cut) {
+    const size_t n = (size_t)sx * sx * 3;
+    char pfmname[1100];
+    snprintf(pfmname, sizeof(pfmname), "%s.pfm", name);
+    FILE *f = fopen(pfmname, "w");
+    if (f) {
+        fprintf(f, "PF\n%d %d\n%1.1f\n", sx, sx, -1.0);
+        fwrite(im, n * sizeof(double), 1, f);
+        fclose(f);
+    }
+    fprintf(stderr, "Image stats: Minimum=%f, maximum=%f\n", mi, mx);
+    fprintf(stderr, "Limit values chosen at min=%f, max=%f... normalizing image\n", low_cut, high_cut);
+    f = fopen(name, "wb+");
+    if (!f) {
+        fprintf(stderr, "Unable to open file %s for output! No image written\n", name);
+    } else {
+        fprintf(f, "P6\n# Output from PathTracer.c\n%d %d\n255\n", sx, sx);
+        fwrite(bits, n, 1, f);
+        fclose(f);
+    }
+}
+
 void dataOutput(double *im, int sx, char *name) {
     const size_t n = (size_t)sx * sx * 3;
     double *t = (double *)malloc(n * sizeof(double));
