@@ -69,6 +69,28 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
     return v * fast_rsqrt(dot3(v, v));
 }
+// Natural logarithm, error below 1 ulp for positive normal x: the argument reduction and polynomial of the
+// classic fdlibm log (x = 2^k * m, sqrt(1/2) <= m < sqrt(2); s = f/(2+f), f = m-1), with the division done by
+// fast_rcp.  About half the instructions of the library routine.  Zero, negative, huge and NaN arguments (which
+// the callers meet only in corrupt paths) take the library routine.
+__device__ __forceinline__ double lean_log(double x) {
+    if (!(x > 2.3e-308 && x < 1e300)) return log(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f * fast_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
 __device__ __forceinline__ double comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
 // ---------------------------------------------------------------- scene
@@ -592,7 +614,7 @@ __device__ __forceinline__ V3 uniform_hemisphere_sample(V3 n, Rng &rng) {
 __device__ __forceinline__ double random_normal(Rng &rng) {
     double ul = rng.next();
     double uc = rng.next();
-    return sqrt(-2 * log(ul)) * cospi(PT_TWO_PI_OVER_PI * uc);
+    return fast_sqrt(-2 * lean_log(ul)) * cospi(PT_TWO_PI_OVER_PI * uc);
 }
 
 // ------------------------------------------------------------ path state
@@ -697,7 +719,7 @@ __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore
         ps.ridx = ps.ridx + 1;
         rindex_store(ps, ls, ps.ridx, obj, obj_r_index, cnt.oob);
     }
-    ps.d = norm3(ps.d * r + rn * (r * c - sqrt(disc)));
+    ps.d = norm3(ps.d * r + rn * (r * c - fast_sqrt(disc)));
 }
 
 // Everything of a new path except its ray: initRay (reference utils_path.h:211-230) and PathTrace's initial

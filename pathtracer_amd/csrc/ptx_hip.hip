@@ -30,7 +30,8 @@
 #endif
 
 // ------------------------------------------------------------------ kernels
-template <int FLAGS, bool USE_BVH>
+// PINHOLE: the aperture is zero, so every sample of a pixel starts along the same direction.
+template <int FLAGS, bool USE_BVH, bool PINHOLE>
 __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
              unsigned long long *__restrict__ stats) {
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
     Path ps;
     bool alive = false;
     int k = inside ? k0 : k1;
-    const bool cache_primary = rp.aperture == 0;
+    constexpr bool cache_primary = PINHOLE;
     if (cache_primary && inside) {
         primary_ray(sc, rp, ls, i, j, k0, ps);
         ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
                 for (int q = 0; q < pending; q++) {
                     double cr = ls.get(LS_PENDING + 3 * q), cg = ls.get(LS_PENDING + 3 * q + 1),
                            cb = ls.get(LS_PENDING + 3 * q + 2);
-                    double f = exp2(-log(wt));
+                    double f = exp2(-lean_log(wt));
                     ar += cr * f;
                     ag += cg * f;
                     ab += cb * f;
@@ -554,8 +555,12 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
         constexpr int F = decltype(fl)::value;
         constexpr bool B = decltype(bv)::value;
-        hipLaunchKernelGGL((k_render<F, B>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk, c->d_rgb,
-                           c->d_wght, c->d_stats);
+        if (c->rp.aperture == 0)
+            hipLaunchKernelGGL((k_render<F, B, true>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk,
+                               c->d_rgb, c->d_wght, c->d_stats);
+        else
+            hipLaunchKernelGGL((k_render<F, B, false>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk,
+                               c->d_rgb, c->d_wght, c->d_stats);
     });
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, c->stream));
