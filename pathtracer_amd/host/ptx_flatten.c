@@ -234,7 +234,24 @@ int ptxh_flatten(ptx_scene_desc *out) {
         il_push(&all, n);
         n++;
     }
-    build(&all);
+    const char *flat = getenv("PTX_FLAT_ORDER");
+    if (flat && *flat && strcmp(flat, "0") != 0) {
+        /* No BoxTree: every object, in object_list order, under one node.  For scenes far beyond what the
+         * reference's builder was made for (it samples pivots above 1000 objects and above 100000 splits at the
+         * middle, magic.c:154-171); nothing is lost and equal-lambda ties go to the earlier list entry. */
+        struct Box b = list_box(&all);
+        g_nodes = (ptx_node *)calloc(1, sizeof(ptx_node));
+        g_nnodes = g_nodecap = 1;
+        memcpy(g_nodes[0].box, &b, sizeof(double) * 6);
+        g_nodes[0].child1 = g_nodes[0].child2 = -1;
+        g_nodes[0].first_obj = 0;
+        g_nodes[0].n_objs = n;
+        for (int k = 0; k < n; k++) g_order[k] = k;
+        g_norder = n;
+        free(all.v);
+    } else {
+        build(&all);
+    }
 
     /* light weights (PathTracer.c:600-611): surfaceArea is the raw weight, LSweight its share of the total.  The
      * kit's objects are left as they are, so flattening twice gives the same result. */

@@ -8,14 +8,16 @@
 void buildScene_cornell(void);
 void buildScene_scifi(void);
 void buildScene_bubbletea(void);
+void buildScene_meshstress(void);
 
-/* Builds the named scene ("cornell", "scifi", "bubbletea") with the kit and flattens it.  Assets (./Textures,
+/* Builds the named scene ("cornell", "scifi", "bubbletea", "meshstress") with the kit and flattens it.  Assets (./Textures,
  * objs/) are looked up relative to the current directory, as in the reference.  Returns 0 or -1. */
 int ptxh_build_scene(const char *name, ptx_scene_desc *out) {
     ptxh_reset();
     if (!strcmp(name, "cornell")) buildScene_cornell();
     else if (!strcmp(name, "scifi")) buildScene_scifi();
     else if (!strcmp(name, "bubbletea")) buildScene_bubbletea();
+    else if (!strcmp(name, "meshstress")) buildScene_meshstress();
     else return -1;
     return ptxh_flatten(out);
 }

@@ -180,6 +180,42 @@ def test_converged_image_within_one_percent_of_oracle(gpu, oracles):
     assert block_rrmse(rgb, same, sx, block) <= 0.75 * floor
 
 
+def test_triangle_mesh_scene_built_by_the_host_kit(tmp_path, oracles):
+    """The mesh stress scene at a small size (2 x 2 x 14 x 14 triangles, through the hierarchy), built by the host
+    kit in flat order: first hits and a render against the oracle on the same flat scene."""
+    import ctypes as C
+    import subprocess
+    import sys
+
+    from harness import Oracle
+
+    out = str(tmp_path / "mesh.ptxscene")
+    code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); lib.ptxh_build_scene_file.argtypes=[ctypes.c_char_p,ctypes.c_char_p];"
+            "sys.exit(0 if lib.ptxh_build_scene_file(b'meshstress', sys.argv[2].encode())==0 else 1)")
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracer_amd", "lib", "libptx_host.so")
+    subprocess.run([sys.executable, "-c", code, lib_path, out], check=True,
+                   env=dict(os.environ, PTX_FLAT_ORDER="1", PTX_MESH_N="14"))
+    sc = pt.Scene.from_file(out)
+    assert len(sc.objects) == 6 + 4 * 14 * 14
+    dev = pt.Device(0)
+    dev.scene_upload(sc)
+    orc = Oracle(sc)
+    rays = random_rays(sc, 20000, 9)
+    compare_hits(dev.first_hit(rays), orc.first_hit(rays), sc, max_id_mismatch=2)
+    sx, spp = 40, 4
+    prm = pt.make_params(sx, 8, ALL, 0.0, seed=4)
+    dev.render_begin(prm)
+    dev.render_passes(0, spp)
+    rgb, _ = dev.download()
+    want, _, st = orc.render(prm, 0, spp)
+    keep = ~diagonal_mask(sx)
+    diff = np.abs(rgb.reshape(-1, 3) - want.reshape(-1, 3)).max(axis=1)
+    tol = 1e-9 + 1e-7 * np.abs(want.reshape(-1, 3)).max(axis=1)
+    assert float((diff[keep] > tol[keep]).mean()) <= MAX_PATH_MISMATCH * spp
+    assert dev.stats()["paths"] == st["paths"]
+    dev.close()
+
+
 def test_errors_are_reported(gpu, scenes):
     dev = pt.Device(0)
     with pytest.raises(pt.PtxError):

@@ -26,14 +26,15 @@ def asset_dir(tmp_path_factory):
     return str(d), have_mesh
 
 
-def build_with_kit(name, cwd, out_path):
+def build_with_kit(name, cwd, out_path, env=None):
     # a child process: the kit keeps its scene in globals and chdir is process-wide
     code = (
         "import ctypes,sys,os; os.chdir(sys.argv[3]); lib=ctypes.CDLL(sys.argv[1]);"
         "lib.ptxh_build_scene_file.argtypes=[ctypes.c_char_p,ctypes.c_char_p];"
         "sys.exit(0 if lib.ptxh_build_scene_file(sys.argv[2].encode(), sys.argv[4].encode())==0 else 1)"
     )
-    subprocess.run(["python3", "-c", code, HOST_LIB, name, cwd, out_path], check=True, capture_output=True)
+    subprocess.run(["python3", "-c", code, HOST_LIB, name, cwd, out_path], check=True, capture_output=True,
+                   env=dict(os.environ, **(env or {})))
     return Scene.from_file(out_path)
 
 
@@ -108,3 +109,23 @@ def test_tone_mapped_output_matches_reference_run(tmp_path):
     lib.dataOutput(acc.ctypes.data_as(C.POINTER(C.c_double)), 24, mine.encode())
     assert open(mine, "rb").read() == ref_ppm
     assert open(mine + ".pfm", "rb").read() == header + acc.tobytes()
+
+
+def test_flat_order_keeps_every_object_in_list_order(tmp_path):
+    """PTX_FLAT_ORDER=1 (scenes too large for the reference's BoxTree builder): one node, nothing lost, objects in
+    the order of the reference's object list (first inserted, then the others from last to second,
+    utils_path.c:125-149); without it the BoxTree restatement runs and reorders."""
+    n = 6
+    flat = build_with_kit("meshstress", str(tmp_path), str(tmp_path / "flat.ptxscene"),
+                          env={"PTX_FLAT_ORDER": "1", "PTX_MESH_N": str(n)})
+    n_obj = 6 + 2 * 2 * n * n
+    assert len(flat.objects) == n_obj and len(flat.nodes) == 1
+    assert int(flat.nodes[0]["n_objs"]) == n_obj and int(flat.nodes[0]["child1"]) == -1
+    assert flat.objects["src_id"].tolist() == [0] + list(range(n_obj - 1, 0, -1))
+    assert (flat.objects["type"] == abi.TRIANGLE).sum() == n_obj - 6
+    tree = build_with_kit("meshstress", str(tmp_path), str(tmp_path / "tree.ptxscene"),
+                          env={"PTX_FLAT_ORDER": "0", "PTX_MESH_N": str(n)})
+    assert len(tree.nodes) > 1 and len(tree.objects) <= n_obj
+    assert sorted(tree.objects["src_id"].tolist()) == sorted(set(tree.objects["src_id"].tolist()))
+    b = flat.objects["box"]
+    assert np.allclose(flat.nodes[0]["box"], [b[:, 0].min(), b[:, 1].max(), b[:, 2].min(), b[:, 3].max(), b[:, 4].min(), b[:, 5].max()])
