@@ -28,3 +28,26 @@ int ptxh_build_scene_file(const char *name, const char *path) {
     if (ptxh_build_scene(name, &d) != 0) return -1;
     return ptx_scene_write(path, &d);
 }
+
+/* A triangle mesh file in a plain setting, written to a scene file: the Cornell camera, one plane light above,
+ * the mesh with the identity transform and a grey diffuse material, every object kept in list order.  For
+ * looking at a mesh and for testing loadObj(). */
+int ptxh_obj_scene_file(const char *obj_path, const char *path) {
+    ptxh_reset();
+    struct point3D e = {0, 0, -15, 1}, g = {0, 0, 15, 1}, up = {0, 1, 0, 1};
+    cam = setupView(&e, &g, &up, -3, -2, 2, 4, -20);
+    if (!cam) return -1;
+    struct object3D *l = newPlane(1, 0, 0, 1, 1, 1, 0, 1.54);
+    Scale(l, .5, 2.5, 1);
+    RotateX(l, PI / 2);
+    Translate(l, 0, 9.995, 5);
+    invert(&l->T[0][0], &l->Tinv[0][0]);
+    l->isLightSource = 1;
+    insertObject(l, &object_list);
+    double T[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    loadObj(obj_path, 1, 0, 0, .7, .7, .7, 0, 1, &object_list, T);
+    setenv("PTX_FLAT_ORDER", "1", 1);
+    ptx_scene_desc d;
+    if (ptxh_flatten(&d) != 0) return -1;
+    return ptx_scene_write(path, &d);
+}

@@ -333,7 +333,7 @@ void loadTexture(struct object3D *o, const char *filename, int type, struct text
 
 /* ---------------------------------------------------------------- meshes */
 
-/* loadObj (meshes.c:23-101): reads "v x y z" and "f a b c" lines (1-based indices, no slashes, lines up to 127
+/* loadObj (meshes.c:23-101): reads "v x y z" and "f a b c" lines (1-based indices, lines up to 127
  * characters); every face becomes one triangle object with its vertices pre-multiplied by T and the given
  * material.  The reference reads the file in four consecutive sweeps (v, vt, vn, f) without rewinding between
  * them, which is reproduced by the running line cursor. */
@@ -378,8 +378,18 @@ void loadObj(const char *fname, double diff, double refl, double tran, double r,
     while (i < fcount && cur < n_lines) {
         const char *ln = lines[cur++];
         if (strncmp(ln, "f ", 2)) continue;
+        /* "f a b c" as the reference reads it; "f a/t/n b/t/n c/t/n" (which its sscanf stops at) is accepted too:
+         * the vertex index is the number before the first slash */
         int vi[3] = {1, 1, 1};
-        sscanf(ln, "f %d %d %d", vi, vi + 1, vi + 2);
+        const char *q0 = ln + 2;
+        for (int q = 0; q < 3; q++) {
+            char *end;
+            long v = strtol(q0, &end, 10);
+            if (end == q0) break;
+            vi[q] = (int)v;
+            while (*end && *end != ' ' && *end != '\t' && *end != '\n') end++;
+            q0 = end;
+        }
         struct point3D p[3];
         for (int q = 0; q < 3; q++) {
             int idx = vi[q] - 1;

@@ -129,3 +129,33 @@ def test_flat_order_keeps_every_object_in_list_order(tmp_path):
     assert sorted(tree.objects["src_id"].tolist()) == sorted(set(tree.objects["src_id"].tolist()))
     b = flat.objects["box"]
     assert np.allclose(flat.nodes[0]["box"], [b[:, 0].min(), b[:, 1].max(), b[:, 2].min(), b[:, 3].max(), b[:, 4].min(), b[:, 5].max()])
+
+
+def test_load_obj_reads_plain_and_slashed_faces(tmp_path):
+    """loadObj: `f a b c` as the reference reads it (meshes.c:81-99), and `f a/t/n b/t/n c/t/n`, which the reference's
+    sscanf cannot read, give the same triangles; vt/vn lines between the blocks are skipped."""
+    verts = [(0, 0, 5), (1, 0, 5), (1, 1, 6), (0, 1, 6), (0.5, 2, 7)]
+    faces = [(1, 2, 3), (1, 3, 4), (4, 3, 5)]
+    plain = tmp_path / "plain.obj"
+    slashed = tmp_path / "slashed.obj"
+    head = "# test mesh\n" + "".join(f"v {x} {y} {z}\n" for x, y, z in verts)
+    extra = "vt 0 0\nvt 1 0\nvn 0 0 1\n"
+    plain.write_text(head + extra + "".join(f"f {a} {b} {c}\n" for a, b, c in faces))
+    slashed.write_text(head + extra + "".join(f"f {a}/1/1 {b}/2/1 {c}//1\n" for a, b, c in faces))
+    lib = C.CDLL(HOST_LIB)
+    lib.ptxh_obj_scene_file.argtypes = [C.c_char_p, C.c_char_p]
+    scenes = []
+    for src in (plain, slashed):
+        out = str(tmp_path / (src.stem + ".ptxscene"))
+        code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); lib.ptxh_obj_scene_file.argtypes=[ctypes.c_char_p,ctypes.c_char_p];"
+                "sys.exit(0 if lib.ptxh_obj_scene_file(sys.argv[2].encode(), sys.argv[3].encode())==0 else 1)")
+        subprocess.run(["python3", "-c", code, HOST_LIB, str(src), out], check=True, capture_output=True)
+        scenes.append(Scene.from_file(out))
+    a, b = scenes
+    assert len(a.objects) == 1 + len(faces) == len(b.objects)
+    assert np.array_equal(a.objects["v"], b.objects["v"]) and np.array_equal(a.objects["box"], b.objects["box"])
+    tris = a.objects[a.objects["type"] == abi.TRIANGLE]
+    by_id = {int(t["src_id"]): t for t in tris}
+    for k, f in enumerate(faces):
+        got = by_id[k + 1]["v"][:, :3]
+        assert np.array_equal(got, np.array([verts[i - 1] for i in f], dtype=float))
