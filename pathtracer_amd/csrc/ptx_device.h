@@ -112,6 +112,12 @@ struct DevGeom {
     double pad;
 };
 static_assert(sizeof(DevGeom) == 160, "DevGeom layout");
+// The always-tested list is read through the constant address space: the scene is never written while a kernel
+// runs, and a load from that address space with a wave-uniform address is a scalar load whatever else the kernel
+// does (a barrier, an atomic or an opaque asm in a loop makes the compiler turn such loads from global memory
+// into per-lane loads).
+#define PTX_CONSTANT_AS __attribute__((address_space(4)))
+typedef const PTX_CONSTANT_AS DevGeom *ConstGeomPtr;
 
 // Shading record, 96 bytes, read per lane for the primitive that was hit.
 struct DevMat {
@@ -213,16 +219,19 @@ struct LaneStore {
     const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]}
 
 // ------------------------------------------------------- transforms
-__device__ __forceinline__ V3 xform_point(const double *m, V3 p) {
+template <typename MP>
+__device__ __forceinline__ V3 xform_point(MP m, V3 p) {
     return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
-__device__ __forceinline__ V3 xform_dir(const double *m, V3 d) {
+template <typename MP>
+__device__ __forceinline__ V3 xform_dir(MP m, V3 d) {
     return mk(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[4] * d.x + m[5] * d.y + m[6] * d.z,
               m[8] * d.x + m[9] * d.y + m[10] * d.z);
 }
 // normalTransform (reference utils_path.c:58-76): direction of Tinv^T n.
-__device__ __forceinline__ V3 xform_normal(const double *m, V3 n) {
+template <typename MP>
+__device__ __forceinline__ V3 xform_normal(MP m, V3 n) {
     return norm3(mk(m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
                     m[2] * n.x + m[6] * n.y + m[10] * n.z));
 }
@@ -237,7 +246,8 @@ __device__ __forceinline__ V3 xform_normal(const double *m, V3 n) {
 __device__ __forceinline__ double sphere_roots(double l1, double l2) { return l2 > PT_TOL ? l2 : l1; }
 
 // sphereIntersect, reference utils_path.c:546-587, in object space
-__device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
+template <typename MP>
+__device__ __forceinline__ double isect_sphere(MP m, V3 p0, V3 d) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double A = dot3(td, td), B = dot3(tp, td), C = dot3(tp, tp) - 1.0;
     double disc = B * B - A * C;
@@ -251,9 +261,10 @@ __device__ __forceinline__ double isect_sphere(const double *m, V3 p0, V3 d) {
 // p' = (p0-c)/r and d' = d/r the reference's A, B, C are (d.d, oc.d,
 // oc.oc - r^2)/r^2 and the roots are unchanged.  inv_dd = 1/(d.d) is shared
 // by all spheres of one ray.
-__device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, V3 d, double dd, double inv_dd) {
-    V3 oc = mk(p0.x - g.c[0], p0.y - g.c[1], p0.z - g.c[2]);
-    double B = dot3(oc, d), C = dot3(oc, oc) - g.e[0];
+template <typename GP>
+__device__ __forceinline__ double isect_sphere_uniform(GP g, V3 p0, V3 d, double dd, double inv_dd) {
+    V3 oc = mk(p0.x - g->c[0], p0.y - g->c[1], p0.z - g->c[2]);
+    double B = dot3(oc, d), C = dot3(oc, oc) - g->e[0];
     double disc = B * B - dd * C;
     if (disc < 0.0) return -1.0;
     double sq = fast_sqrt(disc);
@@ -263,7 +274,8 @@ __device__ __forceinline__ double isect_sphere_uniform(const DevGeom &g, V3 p0, 
 }
 
 // planeIntersect + planeHelper, reference utils_path.c:439-544
-__device__ __forceinline__ double isect_plane(const double *m, V3 p0, V3 d) {
+template <typename MP>
+__device__ __forceinline__ double isect_plane(MP m, V3 p0, V3 d) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     if (fabs(td.z) < PT_TOL) return -1.0;
     double lam = -tp.z / td.z;
@@ -274,7 +286,8 @@ __device__ __forceinline__ double isect_plane(const double *m, V3 p0, V3 d) {
 
 // cubeIntersect / roomIntersect, reference utils_path.c:832-995, :997-1143:
 // faces tried in the order +z -z +y -y +x -x, strictly smaller lambda wins.
-__device__ __forceinline__ double isect_box(const double *m, V3 p0, V3 d, int &part) {
+template <typename MP>
+__device__ __forceinline__ double isect_box(MP m, V3 p0, V3 d, int &part) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double best = INFINITY;
     part = -1;
@@ -297,7 +310,8 @@ __device__ __forceinline__ double isect_box(const double *m, V3 p0, V3 d, int &p
 }
 
 // cylIntersect, reference utils_path.c:625-779.  part: 0 wall, 1 z=-1 cap, 2 z=+1 cap.
-__device__ __forceinline__ double isect_cyl(const double *m, V3 p0, V3 d, int &part) {
+template <typename MP>
+__device__ __forceinline__ double isect_cyl(MP m, V3 p0, V3 d, int &part) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double best = INFINITY;
     part = -1;
@@ -327,7 +341,8 @@ __device__ __forceinline__ double isect_cyl(const double *m, V3 p0, V3 d, int &p
 
 // triangleIntersect, reference utils_path.c:781-830.  part: 1 if the stored
 // normal must be flipped to face the ray.
-__device__ __forceinline__ double isect_triangle(const double *m, V3 p0, V3 d, int &part) {
+template <typename MP>
+__device__ __forceinline__ double isect_triangle(MP m, V3 p0, V3 d, int &part) {
     V3 p1 = mk(m[0], m[1], m[2]), p2 = mk(m[3], m[4], m[5]), p3 = mk(m[6], m[7], m[8]);
     V3 n = mk(m[9], m[10], m[11]);
     double ddn = dot3(n, d);
@@ -351,15 +366,18 @@ struct Hit {
 };
 
 // lambda of one primitive for one ray (dd = d.d, inv_dd = 1/dd)
-__device__ __forceinline__ double isect_any(const DevGeom &g, V3 p0, V3 d, double dd, double inv_dd, int &part) {
+// g: pointer to the geometry record, in global memory (per lane) or, for the always-tested list, in the constant
+// address space (ConstGeomPtr)
+template <typename GP>
+__device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double inv_dd, int &part) {
     part = 0;
-    if (g.fast) return isect_sphere_uniform(g, p0, d, dd, inv_dd);
-    switch (g.type) {
-    case PTX_SPHERE: return isect_sphere(g.m, p0, d);
-    case PTX_PLANE: return isect_plane(g.m, p0, d);
-    case PTX_TRIANGLE: return isect_triangle(g.m, p0, d, part);
-    case PTX_CYL: return isect_cyl(g.m, p0, d, part);
-    default: return isect_box(g.m, p0, d, part);  // PTX_CUBE, PTX_ROOM
+    if (g->fast) return isect_sphere_uniform(g, p0, d, dd, inv_dd);
+    switch (g->type) {
+    case PTX_SPHERE: return isect_sphere(&g->m[0], p0, d);
+    case PTX_PLANE: return isect_plane(&g->m[0], p0, d);
+    case PTX_TRIANGLE: return isect_triangle(&g->m[0], p0, d, part);
+    case PTX_CYL: return isect_cyl(&g->m[0], p0, d, part);
+    default: return isect_box(&g->m[0], p0, d, part);  // PTX_CUBE, PTX_ROOM
     }
 }
 
@@ -379,10 +397,12 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     h.part = 0;
     const double dd = dot3(d, d);
     const double inv_dd = fast_rcp(dd);
+    const ConstGeomPtr list_geom = (ConstGeomPtr)sc.list_geom;
+    const PTX_CONSTANT_AS int32_t *list_ids = (const PTX_CONSTANT_AS int32_t *)sc.list_ids;
     for (int k = 0; k < sc.n_list; k++) {
         int part;
-        const int id = USE_BVH ? sc.list_ids[k] : k;
-        double lam = isect_any(sc.list_geom[k], p0, d, dd, inv_dd, part);
+        const int id = USE_BVH ? list_ids[k] : k;
+        double lam = isect_any(list_geom + k, p0, d, dd, inv_dd, part);
         if (id != os && lam > PT_TOL && lam < h.lambda) {
             h.lambda = lam;
             h.obj = id;
@@ -407,7 +427,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
                 next = node + 1;
                 if (id >= 0 && id != os) {
                     int part;
-                    double lam = isect_any(sc.geom[id], p0, d, dd, inv_dd, part);
+                    double lam = isect_any(&sc.geom[id], p0, d, dd, inv_dd, part);
                     if (lam > PT_TOL && (lam < h.lambda || (lam == h.lambda && id < h.obj))) {
                         h.lambda = lam;
                         h.obj = id;
