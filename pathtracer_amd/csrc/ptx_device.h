@@ -252,8 +252,9 @@ __device__ __forceinline__ double isect_sphere(MP m, V3 p0, V3 d) {
     double A = dot3(td, td), B = dot3(tp, td), C = dot3(tp, tp) - 1.0;
     double disc = B * B - A * C;
     if (disc < 0.0) return -1.0;
-    double sq = sqrt(disc);
-    double mb = -B / A, sa = sq / A;
+    double sq = fast_sqrt(disc);
+    const double inv_a = fast_rcp(A);  // A = |d'|^2 > 0
+    double mb = -B * inv_a, sa = sq * inv_a;
     return sphere_roots(mb + sa, mb - sa);
 }
 
@@ -278,7 +279,7 @@ template <typename MP>
 __device__ __forceinline__ double isect_plane(MP m, V3 p0, V3 d) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     if (fabs(td.z) < PT_TOL) return -1.0;
-    double lam = -tp.z / td.z;
+    double lam = -tp.z * fast_rcp(td.z);  // |td.z| >= TOL here
     if (!(fabs(tp.x + lam * td.x) <= 1.0 - PT_TOL)) return -1.0;
     if (!(fabs(tp.y + lam * td.y) <= 1.0 - PT_TOL)) return -1.0;
     return lam;
@@ -297,7 +298,7 @@ __device__ __forceinline__ double isect_box(MP m, V3 p0, V3 d, int &part) {
         const double s = (f & 1) ? -1.0 : 1.0;
         double da = comp(td, a), pa = comp(tp, a);
         if (fabs(da) < PT_TOL) continue;
-        double lam = (s - pa) / da;
+        double lam = (s - pa) * fast_rcp(da);  // |da| >= TOL here
         const int b = (a + 1) % 3, c = (a + 2) % 3;
         if (!(fabs(comp(tp, b) + lam * comp(td, b)) <= 1.0 - PT_TOL)) continue;
         if (!(fabs(comp(tp, c) + lam * comp(td, c)) <= 1.0 - PT_TOL)) continue;
@@ -348,7 +349,7 @@ __device__ __forceinline__ double isect_triangle(MP m, V3 p0, V3 d, int &part) {
     double ddn = dot3(n, d);
     part = ddn > 0 ? 1 : 0;
     if (-PT_TOL < ddn && ddn < PT_TOL) return -1.0;
-    double lam = dot3(p1 - p0, n) / ddn;
+    double lam = dot3(p1 - p0, n) * fast_rcp(ddn);  // |ddn| >= TOL here
     if (!(lam > 0)) return -1.0;
     V3 poi = p0 + d * lam;
     V3 e12 = p2 - p1, e23 = p3 - p2, e31 = p1 - p3, e13 = p3 - p1, e32 = p2 - p3, e21 = p1 - p2;
