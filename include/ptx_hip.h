@@ -89,6 +89,13 @@ int ptx_sync(ptx_context *ctx);
  * dataOutput() (PathTracer.c:655, :661). */
 int ptx_download(ptx_context *ctx, double *rgbIm, double *wght);
 
+/* Device self-check of the arithmetic that stands in for IEEE divisions and libm routines on the hot path; no
+ * counterpart in the reference.  results[0]: number of (byte, divisor) pairs, 0..255 / 1..255, for which the
+ * texel conversion differs from the reference's byte/divisor (utils_path.c:1849) -- must be 0.  results[1..4]:
+ * largest error, in units in the last place, of the logarithm, square root, reciprocal and reciprocal square
+ * root used in place of log, sqrt, 1/x and 1/sqrt(x). */
+int ptx_selftest(ptx_context *ctx, double results[5]);
+
 /* What dataOutput() prints and chooses while tone mapping (reference utils_path.c:2011-2047): the minimum and
  * maximum of the accumulator values, and the low and high cut picked from the 1000-bin histogram. */
 typedef struct ptx_tonemap_info {

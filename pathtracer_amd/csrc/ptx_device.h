@@ -66,6 +66,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     double e = fma(-x * y, y, 1.0);
     return fma(y * e, fma(0.375, e, 0.5), y);
 }
+// 1/x as the box test wants it: +-infinity for a zero component, like the IEEE division
+__device__ __forceinline__ double rcp_or_inf(double x) { return x == 0.0 ? copysign(INFINITY, x) : fast_rcp(x); }
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
     return v * fast_rsqrt(dot3(v, v));
 }
@@ -411,7 +413,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         }
     }
     if (USE_BVH) {
-        const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;  // IEEE division: a zero component gives +-inf
+        const double ix = rcp_or_inf(d.x), iy = rcp_or_inf(d.y), iz = rcp_or_inf(d.z);
         int node = 0;
         const int n_nodes = sc.n_bvh_nodes;
         while (node < n_nodes) {
@@ -523,9 +525,17 @@ __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 
 }
 
 // ------------------------------------------------------ texture look-ups
-__device__ __forceinline__ double texel_at(const DevScene &sc, const DevImage &im, long idx, long n) {
+// byte / divisor, rounded as the IEEE division the reference performs when it loads an image
+// (utils_path.c:1849, :1921): quotient from the reciprocal (inv = fast_rcp(divisor)), then one correction with
+// the exact remainder.  Equal to the division for every byte and every integer divisor 1..255 (checked
+// exhaustively by ptx_selftest).
+__device__ __forceinline__ double texel_value(double byte, double divisor, double inv) {
+    const double q = byte * inv;
+    return fma(fma(-q, divisor, byte), inv, q);
+}
+__device__ __forceinline__ double texel_at(const DevScene &sc, const DevImage &im, double inv, long idx, long n) {
     idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
-    return (double)sc.texels[im.offset + idx] / im.divisor;
+    return texel_value((double)sc.texels[im.offset + idx], im.divisor, inv);
 }
 // texMap, reference utils_path.c:1322-1374 (flat index clamped to the image
 // buffer where the reference reads out of bounds).
@@ -535,13 +545,14 @@ __device__ __forceinline__ void tex_map(const DevScene &sc, int img, double a, d
     int x1 = (int)x, y1 = (int)y;
     int x2 = x1 + 1, y2 = y1 + 1;
     long n = (long)im.sx * im.sy * 3;
+    const double inv = fast_rcp(im.divisor);
     double out[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        double c11 = texel_at(sc, im, 3L * ((long)y1 * im.sx + x1) + c, n);
-        double c12 = texel_at(sc, im, 3L * ((long)y2 * im.sx + x1) + c, n);
-        double c21 = texel_at(sc, im, 3L * ((long)y1 * im.sx + x2) + c, n);
-        double c22 = texel_at(sc, im, 3L * ((long)y2 * im.sx + x2) + c, n);
+        double c11 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x1) + c, n);
+        double c12 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x1) + c, n);
+        double c21 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x2) + c, n);
+        double c22 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x2) + c, n);
         double avg1 = c11 * (x2 - x) + c21 * (x - x1);
         double avg2 = c12 * (x2 - x) + c22 * (x - x1);
         out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
@@ -557,10 +568,11 @@ __device__ __forceinline__ double alpha_map(const DevScene &sc, int img, double 
     int x1 = (int)x, y1 = (int)y;
     int x2 = x1 + 1, y2 = y1 + 1;
     long n = (long)im.sx * im.sy;
-    double a11 = texel_at(sc, im, (long)y1 * im.sx + x1, n);
-    double a12 = texel_at(sc, im, (long)y2 * im.sx + x1, n);
-    double a21 = texel_at(sc, im, (long)y1 * im.sx + x2, n);
-    double a22 = texel_at(sc, im, (long)y2 * im.sx + x2, n);
+    const double inv = fast_rcp(im.divisor);
+    double a11 = texel_at(sc, im, inv, (long)y1 * im.sx + x1, n);
+    double a12 = texel_at(sc, im, inv, (long)y2 * im.sx + x1, n);
+    double a21 = texel_at(sc, im, inv, (long)y1 * im.sx + x2, n);
+    double a22 = texel_at(sc, im, inv, (long)y2 * im.sx + x2, n);
     double avg1 = a11 * (x2 - x) + a21 * (x - x1);
     double avg2 = a12 * (x2 - x) + a22 * (x - x1);
     return avg1 * (y2 - y) + avg2 * (y - y1);

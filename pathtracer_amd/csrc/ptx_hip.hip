@@ -186,6 +186,43 @@ __global__ void k_fill(double *p, size_t n, double v) {
     if (q < n) p[q] = v;
 }
 
+// Device self-check of the arithmetic helpers that stand in for IEEE operations or library routines.
+// out[0] byte/divisor pairs (0..255 / 1..255) where texel_value differs from the division
+// out[1..4] largest error in ulp of lean_log, fast_sqrt, fast_rcp, fast_rsqrt against log, sqrt, 1/x, 1/sqrt(x)
+__global__ void k_selftest(double *out) {
+    __shared__ double s_err[5][256];
+    const int t = threadIdx.x;
+    double bad = 0, e_log = 0, e_sqrt = 0, e_rcp = 0, e_rsq = 0;
+    for (int b = 1; b <= 255; b++) {
+        const double inv = fast_rcp((double)b);
+        if (texel_value((double)t, (double)b, inv) != (double)t / (double)b) bad += 1;
+    }
+    uint64_t z = 0x1234567ULL + (uint64_t)t * PTX_GOLDEN + (uint64_t)blockIdx.x * 0x9E3779B1ULL;
+    for (int q = 0; q < 4096; q++) {
+        z += PTX_GOLDEN;
+        const double u = ptx_bits_to_unit(ptx_mix64(z));
+        double x = (q & 3) == 0 ? u : ((q & 3) == 1 ? 1.0 + 4000.0 * u : exp((u - 0.5) * 1200.0));
+        if ((q & 3) == 3) x = 1.0 + (u - 0.5) * 1e-3;
+        if (!(x > 0)) continue;
+        auto ulps = [](double got, double want) {
+            if (got == want) return 0.0;
+            const double ulp = ldexp(1.0, ilogb(want) - 52);
+            return fabs(got - want) / ulp;
+        };
+        e_log = fmax(e_log, x == 1.0 ? fabs(lean_log(x)) * 0x1p52 : ulps(lean_log(x), log(x)));
+        e_sqrt = fmax(e_sqrt, ulps(fast_sqrt(x), sqrt(x)));
+        e_rcp = fmax(e_rcp, ulps(fast_rcp(x), 1.0 / x));
+        e_rsq = fmax(e_rsq, ulps(fast_rsqrt(x), 1.0 / sqrt(x)));
+    }
+    s_err[0][t] = bad; s_err[1][t] = e_log; s_err[2][t] = e_sqrt; s_err[3][t] = e_rcp; s_err[4][t] = e_rsq;
+    __syncthreads();
+    if (t < 5) {
+        double r = 0;
+        for (int q = 0; q < 256; q++) r = t == 0 ? r + s_err[0][q] : fmax(r, s_err[t][q]);
+        out[blockIdx.x * 5 + t] = r;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -597,6 +634,28 @@ extern "C" int ptx_tonemap(ptx_context *c, uint8_t *bits, ptx_tonemap_info *info
     if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
     if (c->rp.rows_owned != c->rp.sx) return fail(PTX_ESTATE, "ptx_tonemap: this rank holds only part of the image");
     return ptx_tonemap_device(c, c->d_rgb, (uint64_t)c->rp.sx * c->rp.sx * 3, bits, info);
+}
+
+extern "C" int ptx_selftest(ptx_context *c, double *results) {
+    if (!c || !results) return fail(PTX_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int blocks = 64;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, blocks * 5 * sizeof(double)));
+    hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(256), 0, c->stream, d_out);
+    std::vector<double> h(blocks * 5);
+    int rc = PTX_OK;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        rc = fail(PTX_EDEVICE, "ptx_selftest: kernel failed");
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    for (int q = 0; q < 5; q++) results[q] = 0;
+    for (int b = 0; b < blocks; b++) {
+        results[0] = h[b * 5];  // the same exhaustive count in every block
+        for (int q = 1; q < 5; q++) results[q] = std::max(results[q], h[b * 5 + q]);
+    }
+    return PTX_OK;
 }
 
 extern "C" int ptx_accumulators(ptx_context *c, double **d_rgb, double **d_wght, int32_t *rows) {

@@ -18,7 +18,7 @@ EXPORTS = [
     "ptx_init", "ptx_shutdown", "ptx_scene_upload", "ptx_render_begin", "ptx_render_begin_external",
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
-    "ptx_tonemap", "ptx_tonemap_device",
+    "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest",
 ]
 
 
@@ -54,6 +54,7 @@ def load_library(path=None):
     lib.ptx_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     lib.ptx_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ptx_set_stream.argtypes = [vp, vp]
+    lib.ptx_selftest.argtypes = [vp, dp]
     lib.ptx_tonemap.argtypes = [vp, vp, C.POINTER(abi.TonemapInfo)]
     lib.ptx_tonemap_device.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(abi.TonemapInfo)]
     lib.ptx_last_error.restype = C.c_char_p
@@ -153,6 +154,11 @@ class Device:
             self._check(self.lib.ptx_tonemap_device(self.ctx, d_im, n_values, bits.ctypes.data, C.byref(info)))
         return bits, {"min": info.min, "max": info.max, "low_cut": info.low_cut, "high_cut": info.high_cut,
                       "recomputed_on_host": info.recomputed_on_host}
+
+    def selftest(self):
+        r = (C.c_double * 5)()
+        self._check(self.lib.ptx_selftest(self.ctx, r))
+        return {"texel_mismatches": r[0], "log_ulp": r[1], "sqrt_ulp": r[2], "rcp_ulp": r[3], "rsqrt_ulp": r[4]}
 
     def stats(self):
         s = abi.Stats()

@@ -216,6 +216,15 @@ def test_triangle_mesh_scene_built_by_the_host_kit(tmp_path, oracles):
     dev.close()
 
 
+def test_device_arithmetic_helpers(gpu):
+    """The stand-ins for IEEE division and libm on the hot path: the texel conversion is the reference's division
+    exactly, the others stay within a unit or two in the last place."""
+    r = gpu["cornell"].selftest()
+    assert r["texel_mismatches"] == 0
+    assert r["log_ulp"] <= 1.5 and r["sqrt_ulp"] <= 1.5 and r["rcp_ulp"] <= 1.5, r
+    assert r["rsqrt_ulp"] <= 2.5, r  # against 1/sqrt(x), itself two roundings away from the exact value
+
+
 def test_errors_are_reported(gpu, scenes):
     dev = pt.Device(0)
     with pytest.raises(pt.PtxError):
