@@ -48,10 +48,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
     e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
-// sqrt(x) for x >= 0, from the hardware reciprocal square root plus Goldschmidt steps.  Arguments below 1e-300
-// (zero, and the negative rounding residue of an expression that is zero in exact arithmetic) give 1e-150.
+// sqrt(|x| + 1e-300), from the hardware reciprocal square root plus Goldschmidt steps: sqrt(x) for x >= 1e-284,
+// 1e-150 for zero, and the root of the magnitude for the negative rounding residue of an expression that is zero
+// in exact arithmetic.
 __device__ __forceinline__ double fast_sqrt(double x) {
-    x = fmax(x, 1e-300);
+    x = fabs(x) + 1e-300;
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
