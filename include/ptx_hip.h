@@ -113,6 +113,12 @@ int ptx_tonemap(ptx_context *ctx, uint8_t *bits, ptx_tonemap_info *info);
 /* The same for any device buffer of n_values doubles (an image gathered from several ranks, for instance). */
 int ptx_tonemap_device(ptx_context *ctx, const double *d_im, uint64_t n_values, uint8_t *bits, ptx_tonemap_info *info);
 
+/* The reverse of ptx_download: sets this rank's rows of the accumulators from whole-image host buffers (the
+ * doubles of a <name>.pfm written earlier and the matching weights), so that a render can be taken up again at
+ * the pass where it stopped.  The reference has no such path (its accumulators live and die with the process,
+ * PathTracer.c:550-557).  Either pointer may be NULL. */
+int ptx_upload(ptx_context *ctx, const double *rgbIm, const double *wght);
+
 /* Device addresses of this rank's accumulators and the number of rows they
  * hold (for a device-side gather).  */
 int ptx_accumulators(ptx_context *ctx, double **d_rgb, double **d_wght, int32_t *rows_owned);

@@ -691,6 +691,29 @@ extern "C" int ptx_download(ptx_context *c, double *rgbIm, double *wght) {
     return PTX_OK;
 }
 
+extern "C" int ptx_upload(ptx_context *c, const double *rgbIm, const double *wght) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const DevRender &r = c->rp;
+    const size_t sx = r.sx;
+    int local = 0;
+    while (local < r.rows_owned) {  // the row bands of ptx_download, in the other direction
+        int g0 = ptx_global_row(local, r.rank, r.n_ranks, r.band_rows);
+        int run = r.n_ranks <= 1 ? r.rows_owned : r.band_rows - local % r.band_rows;
+        if (run > r.rows_owned - local) run = r.rows_owned - local;
+        if (rgbIm)
+            HIPCHK(hipMemcpy(c->d_rgb + (size_t)local * sx * 3, rgbIm + (size_t)g0 * sx * 3, (size_t)run * sx * 3 * sizeof(double),
+                             hipMemcpyHostToDevice));
+        if (wght)
+            HIPCHK(hipMemcpy(c->d_wght + (size_t)local * sx, wght + (size_t)g0 * sx, (size_t)run * sx * sizeof(double),
+                             hipMemcpyHostToDevice));
+        local += run;
+    }
+    return PTX_OK;
+}
+
 extern "C" int ptx_get_stats(ptx_context *c, ptx_stats *st) {
     if (!c || !st) return fail(PTX_EINVAL, "null argument");
     HIPCHK(hipSetDevice(c->device));

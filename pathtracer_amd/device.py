@@ -18,7 +18,7 @@ EXPORTS = [
     "ptx_init", "ptx_shutdown", "ptx_scene_upload", "ptx_render_begin", "ptx_render_begin_external",
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
-    "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest",
+    "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload",
 ]
 
 
@@ -47,6 +47,7 @@ def load_library(path=None):
     lib.ptx_render_passes.argtypes = [vp, C.c_int, C.c_int]
     lib.ptx_sync.argtypes = [vp]
     lib.ptx_download.argtypes = [vp, vp, vp]
+    lib.ptx_upload.argtypes = [vp, vp, vp]
     lib.ptx_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p]
     lib.ptx_first_hit.argtypes = [vp, vp, C.c_int64, vp]
     lib.ptx_first_hit_device.argtypes = [vp, vp, C.c_int64, vp]
@@ -120,6 +121,13 @@ class Device:
             wght = np.ones(sx * sx)
         self._check(self.lib.ptx_download(self.ctx, rgb.ctypes.data, wght.ctypes.data))
         return rgb, wght
+
+    def upload(self, rgb=None, wght=None):
+        """Sets the accumulators from whole-image arrays (sx*sx*3 and sx*sx doubles)."""
+        rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.float64)
+        wght = None if wght is None else np.ascontiguousarray(wght, dtype=np.float64)
+        self._check(self.lib.ptx_upload(self.ctx, None if rgb is None else rgb.ctypes.data,
+                                        None if wght is None else wght.ctypes.data))
 
     def accumulators(self):
         a, b, n = C.c_void_p(), C.c_void_p(), C.c_int32()

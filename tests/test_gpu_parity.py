@@ -216,6 +216,29 @@ def test_triangle_mesh_scene_built_by_the_host_kit(tmp_path, oracles):
     dev.close()
 
 
+def test_render_resumed_from_saved_accumulators(gpu):
+    """ptx_upload: passes 0..5 in one go equal passes 0..2, download, a fresh render_begin, upload, passes 3..5;
+    with two ranks' row bands as well."""
+    dev = gpu["cornell"]
+    sx = 72
+    for n_ranks in (1, 2):
+        whole_rgb, whole_w = np.zeros(sx * sx * 3), np.ones(sx * sx)
+        again_rgb, again_w = np.zeros(sx * sx * 3), np.ones(sx * sx)
+        for rank in range(n_ranks):
+            prm = pt.make_params(sx, 6, ALL, 0.0, seed=8, rank=rank, n_ranks=n_ranks, band_rows=8)
+            dev.render_begin(prm)
+            dev.render_passes(0, 6)
+            dev.download(whole_rgb, whole_w)
+            dev.render_begin(prm)
+            dev.render_passes(0, 3)
+            half_rgb, half_w = dev.download()
+            dev.render_begin(prm)
+            dev.upload(half_rgb, half_w)
+            dev.render_passes(3, 3)
+            dev.download(again_rgb, again_w)
+        assert np.array_equal(whole_rgb, again_rgb) and np.array_equal(whole_w, again_w)
+
+
 def test_device_arithmetic_helpers(gpu):
     """The stand-ins for IEEE division and libm on the hot path: the texel conversion is the reference's division
     exactly, the others stay within a unit or two in the last place."""
