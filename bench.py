@@ -121,6 +121,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be started through torch.distributed.run with N ranks")
     torch.cuda.set_device(local_rank)
+    torch.cuda.init()  # PyTorch's HIP runtime first, then the library's (they are separate copies of the runtime)
+    torch.zeros(1, device=torch.device("cuda", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
