@@ -200,11 +200,13 @@ struct Rng {
 //   4..6    ray3D.srcN x,y,z (reference PathTracer.h:85)
 //   7..9    direction of the pixel's primary ray (the same for every sample when the aperture is zero: the
 //           reference samples pixel centres, PathTracer.c:625-628)
-//   10..18  colours of up to three finished paths waiting to be folded into the accumulator, in sample order
+//   10..    colours of finished paths waiting to be folded into the accumulator, in sample order: three per
+//           path, up to LS_PENDING_MAX paths (the render kernel picks its own ring length per variant)
 // Int slots:
 //   0..9    ray3D.r_index[0..9] (reference PathTracer.h:88), held as the index of the object whose r_index
 //           was pushed (RI_ONE: the initial 1.0 of initRay; RI_ZERO: never written)
-// 19 double + 10 int slots = 12 KiB per wave, twelve waves per CU.
+// 19 double + 10 int slots = 12 KiB per wave (twelve waves per CU); 13 + 10 slots = 9 KiB with a ring of one
+// (sixteen waves per CU).
 enum { LS_ACC = 0, LS_SRCN = 4, LS_PRIMARY_D = 7, LS_PENDING = 10, LS_PENDING_MAX = 3, LS_DSLOTS = LS_PENDING + 3 * LS_PENDING_MAX };
 enum { LS_RINDEX = 0, LS_ISLOTS = 10 };
 enum { RI_ONE = -1, RI_ZERO = -2 };

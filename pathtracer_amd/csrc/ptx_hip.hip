@@ -25,17 +25,27 @@
 #include "ptx_hip.h"
 #include "ptx_internal.h"
 
-#ifndef PTX_RENDER_WAVES_PER_EU
-#define PTX_RENDER_WAVES_PER_EU 3
-#endif
+// Waves per SIMD the render kernel is compiled for, and the length of a lane's ring of finished colours.  The
+// kernel for small scenes with a zero aperture (the benchmark case) needs about 144 registers: held to 128 it
+// spills 68 bytes per lane and runs four waves per SIMD, which is 5 % faster, provided the lane store shrinks to
+// 9 KiB per wave (a ring of one) so that sixteen waves fit a compute unit's LDS.  The variants with a hierarchy
+// or a lens need more registers and lose 10 % that way: three waves, a ring of three.
+template <bool USE_BVH, bool PINHOLE>
+struct RenderShape {
+    static constexpr int waves_per_simd = (USE_BVH || !PINHOLE) ? 3 : 4;
+    static constexpr int pending_max = (USE_BVH || !PINHOLE) ? 3 : 1;
+};
 
 // ------------------------------------------------------------------ kernels
 // PINHOLE: the aperture is zero, so every sample of a pixel starts along the same direction.
 template <int FLAGS, bool USE_BVH, bool PINHOLE>
-__global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
+__global__ void __launch_bounds__(PTX_BLOCK, (RenderShape<USE_BVH, PINHOLE>::waves_per_simd))
     k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
              unsigned long long *__restrict__ stats) {
-    PTX_LANE_STORE(ls);
+    constexpr int PENDING_MAX = RenderShape<USE_BVH, PINHOLE>::pending_max;
+    __shared__ double lds_d_[LS_PENDING + 3 * PENDING_MAX][PTX_BLOCK];
+    __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
+    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (PTX_BLOCK >> 6) + (threadIdx.x >> 6);
     const int tiles_x = (rp.sx + 7) >> 3;
@@ -63,7 +73,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
         ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
     }
     // Finished paths are folded into the accumulator in batches: a lane parks the colour of each finished path
-    // (at most LS_PENDING_MAX of them), and when any lane of the wave has filled its slots every lane folds what it
+    // (at most PENDING_MAX of them), and when any lane of the wave has filled its slots every lane folds what it
     // has, in sample order.  The fold (a log and an exp2 per sample) then runs with most lanes active instead of
     // the quarter that finish in any one iteration.
     int pending = 0;
@@ -76,7 +86,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_RENDER_WAVES_PER_EU)
             ended = rp.max_depth < 1;  // reference PathTracer.c:273 with depth = 1
         }
         const bool any_alive = __ballot(alive) != 0ULL;
-        if (!any_alive || __ballot(pending == LS_PENDING_MAX) != 0ULL) {
+        if (!any_alive || __ballot(pending == PENDING_MAX) != 0ULL) {
             // fold, reference PathTracer.c:646-652
             if (pending > 0) {
                 double ar = ls.get(LS_ACC + 0), ag = ls.get(LS_ACC + 1), ab = ls.get(LS_ACC + 2), wt = ls.get(LS_ACC + 3);
