@@ -8,9 +8,13 @@
 //   2. radix sort   (rocPRIM) of (code, primitive) pairs
 //   3. k_hierarchy  one thread per inner node finds its range and split from the sorted codes
 //   4. k_refit      boxes bottom-up, the second thread to reach a node continues upward
-//   5. k_emit       nodes written in depth-first order with a "skip" link each
+//   5. k_order      per inner node and per octant of ray directions: which child lies nearer
+//   6. k_emit       nodes written in depth-first order with a "skip" link each, once per octant
 // The emitted array is walked without a stack: a node that is hit is followed by the next array entry, a node
-// that is missed (or a leaf that has been tested) by its skip link.
+// that is missed (or a leaf that has been tested) by its skip link.  A fixed order meets the primitives of a ray
+// that travels against it last, after every box along the ray; with one array per octant -- the child that is
+// nearer along the axis separating the two children comes first -- a ray meets its near primitives early and
+// the distance of the best hit culls the rest.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -113,37 +117,74 @@ __global__ void k_refit(const double *__restrict__ boxes, const int *__restrict_
     }
 }
 
-// depth-first position of a node whose leaf range starts at `lo`: 2*lo + (number of ancestors that hold it in their
-// left subtree)
-__device__ inline int preorder_of(int lo, int node_is_leaf, int idx, const int *left, const int *parent_inner,
-                                  const int *parent_leaf) {
-    int count = 0;
+// Bit o of order[i]: for rays of octant o (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0) the right child of inner
+// node i is walked before the left one.  The children are compared along the axis on which their box centres lie
+// furthest apart.
+__global__ void k_order(const double *__restrict__ boxes, const int *__restrict__ ids, int n, const int *__restrict__ left,
+                        const int *__restrict__ right, const double *__restrict__ inner_box, unsigned char *__restrict__ order) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int lc = left[i], rc = right[i];
+    const double *a = lc >= 0 ? inner_box + 6 * (size_t)lc : boxes + 6 * (size_t)ids[~lc];
+    const double *b = rc >= 0 ? inner_box + 6 * (size_t)rc : boxes + 6 * (size_t)ids[~rc];
+    int axis = 0;
+    double sep = 0, best = -1;
+    for (int q = 0; q < 3; q++) {
+        const double dq = (b[2 * q] + b[2 * q + 1]) - (a[2 * q] + a[2 * q + 1]);  // twice the distance of the centres
+        if (fabs(dq) > best) {
+            best = fabs(dq);
+            sep = dq;
+            axis = q;
+        }
+    }
+    const bool left_is_low = sep >= 0;
+    unsigned bits = 0;
+    for (int o = 0; o < 8; o++) {
+        const bool negative = (o >> axis) & 1;
+        if (left_is_low == negative) bits |= 1u << o;  // the ray comes from the right child's side
+    }
+    order[i] = (unsigned char)bits;
+}
+
+__device__ inline int subtree_nodes(int child, const int *first, const int *last) {
+    return child < 0 ? 1 : 2 * (last[child] - first[child] + 1) - 1;
+}
+
+// depth-first position of a node in the order of octant o: one for every ancestor, plus the subtree of the sibling
+// wherever the sibling is walked first
+__device__ inline int preorder_of(int node_is_leaf, int idx, int o, const int *left, const int *right, const int *parent_inner,
+                                  const int *parent_leaf, const int *first, const int *last, const unsigned char *order) {
+    int pos = 0;
     int child = node_is_leaf ? ~idx : idx;
     int p = node_is_leaf ? parent_leaf[idx] : parent_inner[idx];
     while (p >= 0) {
-        if (left[p] == child) count++;
+        const bool is_left = left[p] == child;
+        const bool right_first = (order[p] >> o) & 1;
+        pos += 1;
+        if (is_left == right_first) pos += subtree_nodes(is_left ? right[p] : left[p], first, last);
         child = p;
         p = parent_inner[p];
     }
-    return 2 * lo + count;
+    return pos;
 }
 
 __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__ ids, const int *__restrict__ prim_ids, int n,
-                       const int *__restrict__ left, const int *__restrict__ parent_inner, const int *__restrict__ parent_leaf,
-                       const int *__restrict__ first, const int *__restrict__ last, const double *__restrict__ inner_box,
+                       int o, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
+                       const int *__restrict__ parent_leaf, const int *__restrict__ first, const int *__restrict__ last,
+                       const unsigned char *__restrict__ order, const double *__restrict__ inner_box,
                        PtxBvhNode *__restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * n - 1) return;
     PtxBvhNode node;
     int pre;
     if (t < n - 1) {  // inner node t
-        pre = preorder_of(first[t], 0, t, left, parent_inner, parent_leaf);
+        pre = preorder_of(0, t, o, left, right, parent_inner, parent_leaf, first, last, order);
         for (int q = 0; q < 6; q++) node.box[q] = inner_box[6 * (size_t)t + q];
         node.obj = -1;
         node.skip = pre + 2 * (last[t] - first[t] + 1) - 1;
     } else {  // leaf at sorted position i
         int i = t - (n - 1);
-        pre = n == 1 ? 0 : preorder_of(i, 1, i, left, parent_inner, parent_leaf);
+        pre = n == 1 ? 0 : preorder_of(1, i, o, left, right, parent_inner, parent_leaf, first, last, order);
         const double *b = boxes + 6 * (size_t)ids[i];
         for (int q = 0; q < 6; q++) node.box[q] = b[q];
         node.obj = prim_ids[ids[i]];
@@ -164,11 +205,15 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
 
 }  // namespace
 
-int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, hipStream_t stream, PtxBvhNode **d_nodes_out,
-                  int *n_nodes_out, std::string &err) {
+int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, hipStream_t stream,
+                  PtxBvhNode **d_nodes_out, int *n_nodes_out, std::string &err) {
     *d_nodes_out = nullptr;
     *n_nodes_out = 0;
     if (n <= 0) return 0;
+    if (n_orders != 1 && n_orders != 8) {
+        err = "ptx_bvh_build: one order or eight";
+        return -1;
+    }
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = 0; i < n; i++)
         for (int a = 0; a < 3; a++) {
@@ -183,6 +228,7 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, hipStream
     int *d_prim = nullptr, *d_ids = nullptr, *d_ids2 = nullptr, *d_left = nullptr, *d_right = nullptr, *d_pin = nullptr,
         *d_pleaf = nullptr, *d_first = nullptr, *d_last = nullptr, *d_arrived = nullptr;
     unsigned long long *d_codes = nullptr, *d_codes2 = nullptr;
+    unsigned char *d_order = nullptr;
     void *d_tmp = nullptr;
     PtxBvhNode *d_nodes = nullptr;
     size_t tmp_bytes = 0;
@@ -204,7 +250,9 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, hipStream
     BVHCHK(hipMalloc((void **)&d_arrived, sizeof(int) * (size_t)n_inner));
     BVHCHK(hipMalloc((void **)&d_pleaf, sizeof(int) * (size_t)n));
     BVHCHK(hipMalloc((void **)&d_inner_box, sizeof(double) * 6 * (size_t)n_inner));
-    BVHCHK(hipMalloc((void **)&d_nodes, sizeof(PtxBvhNode) * (size_t)(2 * n - 1)));
+    BVHCHK(hipMalloc((void **)&d_order, (size_t)n_inner));
+    BVHCHK(hipMalloc((void **)&d_nodes, sizeof(PtxBvhNode) * (size_t)(2 * n - 1) * n_orders));
+    BVHCHK(hipMemsetAsync(d_order, 0, (size_t)n_inner, stream));
     BVHCHK(hipMemcpyAsync(d_boxes, h_boxes, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, stream));
     BVHCHK(hipMemcpyAsync(d_prim, h_prim_ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream));
     BVHCHK(hipMemsetAsync(d_arrived, 0, sizeof(int) * (size_t)n_inner, stream));
@@ -222,9 +270,15 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, hipStream
                            d_arrived);
         BVHCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, d_left, d_pin, d_pleaf, d_first, d_last,
-                       d_inner_box, d_nodes);
-    BVHCHK(hipGetLastError());
+    if (n > 1 && n_orders == 8) {
+        hipLaunchKernelGGL(k_order, dim3(gb), dim3(256), 0, stream, d_boxes, d_ids2, n, d_left, d_right, d_inner_box, d_order);
+        BVHCHK(hipGetLastError());
+    }
+    for (int o = 0; o < n_orders; o++) {
+        hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, o, d_left, d_right, d_pin, d_pleaf,
+                           d_first, d_last, d_order, d_inner_box, d_nodes + (size_t)o * (2 * n - 1));
+        BVHCHK(hipGetLastError());
+    }
     BVHCHK(hipStreamSynchronize(stream));
     *d_nodes_out = d_nodes;
     *n_nodes_out = 2 * n - 1;
@@ -233,7 +287,7 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, hipStream
 done:
     for (void *p : {(void *)d_boxes, (void *)d_inner_box, (void *)d_prim, (void *)d_ids, (void *)d_ids2, (void *)d_left,
                     (void *)d_right, (void *)d_pin, (void *)d_pleaf, (void *)d_first, (void *)d_last, (void *)d_arrived,
-                    (void *)d_codes, (void *)d_codes2, d_tmp, (void *)d_nodes})
+                    (void *)d_codes, (void *)d_codes2, (void *)d_order, d_tmp, (void *)d_nodes})
         (void)hipFree(p);
     return rc;
 }

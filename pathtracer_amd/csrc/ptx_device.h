@@ -167,7 +167,8 @@ struct DevScene {
     const DevLight *lights;
     const DevImage *images;
     const uint8_t *texels;
-    int32_t n_objects, n_list, n_bvh_nodes;
+    int32_t n_objects, n_list, n_bvh_nodes;  // n_bvh_nodes: per array
+    int32_t bvh_per_octant;                  // 1: bvh holds eight arrays, one per octant of ray directions
     int32_t n_lights, n_images, has_refraction;
     DevCamera cam;
 };
@@ -419,8 +420,11 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         const double ix = rcp_or_inf(d.x), iy = rcp_or_inf(d.y), iz = rcp_or_inf(d.z);
         int node = 0;
         const int n_nodes = sc.n_bvh_nodes;
+        // the array whose order suits this ray: nearer children first (ptx_bvh.h)
+        const int octant = sc.bvh_per_octant ? ((d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2) : 0;
+        const PtxBvhNode *nodes = sc.bvh + (size_t)octant * (size_t)n_nodes;
         while (node < n_nodes) {
-            const PtxBvhNode &nd = sc.bvh[node];
+            const PtxBvhNode &nd = nodes[node];
             double t0 = (nd.box[0] - p0.x) * ix, t1 = (nd.box[1] - p0.x) * ix;
             double t2 = (nd.box[2] - p0.y) * iy, t3 = (nd.box[3] - p0.y) * iy;
             double t4 = (nd.box[4] - p0.z) * iz, t5 = (nd.box[5] - p0.z) * iz;

@@ -216,6 +216,27 @@ def test_triangle_mesh_scene_built_by_the_host_kit(tmp_path, oracles):
     dev.close()
 
 
+@pytest.mark.parametrize("name", ["scifi", "bubbletea"])
+def test_hierarchy_order_does_not_change_results(name, scenes, monkeypatch):
+    """One node array walked left child first, or eight arrays walked nearer child first: the closest hit is the
+    same primitive at the same distance, so first hits and rendered images are equal bit for bit."""
+    got = {}
+    for orders in ("1", "8"):
+        monkeypatch.setenv("PTX_BVH_ORDERS", orders)
+        dev = pt.Device(0)
+        dev.scene_upload(scenes[name])
+        hits = dev.first_hit(random_rays(scenes[name], 20000, 77))
+        dev.render_begin(pt.make_params(48, 8, ALL, 0.05, seed=3))
+        dev.render_passes(0, 4)
+        rgb, wt = dev.download()
+        got[orders] = (hits, rgb, wt, dev.stats())
+        dev.close()
+    a, b = got["1"], got["8"]
+    assert np.array_equal(a[0]["obj"], b[0]["obj"]) and np.array_equal(a[0]["lambda"], b[0]["lambda"])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3]["paths"] == b[3]["paths"] and a[3]["closest_hits"] == b[3]["closest_hits"]
+
+
 def test_render_resumed_from_saved_accumulators(gpu):
     """ptx_upload: passes 0..5 in one go equal passes 0..2, download, a fresh render_begin, upload, passes 3..5;
     with two ranks' row bands as well."""
