@@ -23,10 +23,10 @@ PEAK_FP32_TFLOPS = 157.3
 
 
 def recorded_hbm_traffic(rows, sx):
-    """HBM bytes of one render launch from the newest counter summary under profiles/ (written by
-    tools/collect_profiles.sh: FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE).  The counters cannot be read
-    from inside this process, so the figure is the recorded one, scaled to this rank's share of the pixels (the
-    traffic is the accumulators, read once and written once per launch whatever the sample count)."""
+    """HBM bytes of one launch of the path-tracing kernel on this workload, from the newest counter summary of it
+    under profiles/ (written by tools/collect_profiles.sh: FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE).
+    The counters cannot be read from inside this process, so the figure is the recorded one, scaled to this rank's
+    share of the pixels (the traffic is the traced samples, 32 bytes each, and spilled registers)."""
     import glob
 
     best = None
@@ -34,6 +34,8 @@ def recorded_hbm_traffic(rows, sx):
         try:
             with open(path) as f:
                 rec = json.load(f)
+            if rec.get("kernel") != "k_trace_samples" or rec.get("workload", "bench") != "bench":
+                continue
             best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path))
         except (OSError, ValueError, KeyError):
             continue
@@ -151,7 +153,7 @@ def main():
             nk = min(chunk, spp - k)
             dev.render_passes(k, nk)
             if record:
-                kernel_ms.append((dev.last_pass_ms(), nk))
+                kernel_ms.append(dev.last_trace_ms() + (nk,))
             k += nk
         return parallel.gather_accumulators(rgb, wght, sx, rank, world, band)
 
@@ -177,9 +179,11 @@ def main():
 
     total_paths = sx * sx * spp * args.steps
     paths_per_s = total_paths / dt
-    # dominant kernel: k_render; per launch it processes rows*sx*nk paths
-    ms_sum = sum(m for m, _ in kernel_ms)
-    paths_launches = sum(rows * sx * nk for _, nk in kernel_ms)
+    # dominant kernel: k_trace_samples; a render_passes call of nk passes launches it once per round of samples
+    # that fits the sample buffer (once, here), and over its launches it traces rows*sx*nk paths
+    ms_sum = sum(m for m, _, _ in kernel_ms)
+    n_launches = sum(n for _, n, _ in kernel_ms)
+    paths_launches = sum(rows * sx * nk for _, _, nk in kernel_ms)
     achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
     rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
     traffic, traffic_src = recorded_hbm_traffic(rows, sx) if sx == 1024 else (None, None)
@@ -212,9 +216,9 @@ def main():
             "frac": achieved_tflops / PEAK_FP32_TFLOPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "algorithmic_hbm_bytes_per_launch": 64 * rows * sx,
-            "kernel": "k_render",
-            "kernel_ms_avg": ms_sum / max(1, len(kernel_ms)),
+            "algorithmic_hbm_bytes_per_launch": 32 * paths_launches // max(1, n_launches),
+            "kernel": "k_trace_samples",
+            "kernel_ms_avg": ms_sum / max(1, n_launches),
             "flop_per_path_model": FLOP_PER_PATH,
             "note": "vector FP32 peak (no MFMA: the work is not a dense contraction); arithmetic runs in FP64 "
                     "(peak 78.6 TFLOP/s), so frac against the FP64 vector peak is twice this value",

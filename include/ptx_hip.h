@@ -142,11 +142,16 @@ int ptx_trace_paths(ptx_context *ctx, const ptx_render_params *params, const int
 /* Counters accumulated since ptx_render_begin (synchronises). */
 int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);
 
-/* Device time in milliseconds of the most recent ptx_render_passes launch,
- * from HIP events recorded on the context's stream around the kernel
+/* Device time in milliseconds of the most recent ptx_render_passes call,
+ * from HIP events recorded on the context's stream around its kernels
  * (synchronises).  The reference times with time(NULL) at 1 s resolution
  * (PathTracer.c:614, :658). */
 int ptx_last_pass_ms(ptx_context *ctx, float *ms);
+
+/* Of that time, the part spent in the path-tracing kernel alone (the rest is the in-order accumulation of the
+ * traced samples), summed over the kernel's launches in that call; *launches, if not NULL, receives their number.
+ * No counterpart in the reference; used to report the kernel against its roofline. */
+int ptx_last_trace_ms(ptx_context *ctx, float *ms, int *launches);
 
 /* Makes the context launch on an existing hipStream_t (passed as void*),
  * e.g. the stream a caller's framework is using.  NULL restores the

@@ -197,18 +197,14 @@ struct Rng {
 // word [s][t], so a wave touches 64 consecutive words (no bank conflicts)
 // and a lane can index its slots dynamically without going to scratch.
 // Double slots:
-//   0..3    radiance accumulator r,g,b and weight of the lane's pixel
-//   4..6    ray3D.srcN x,y,z (reference PathTracer.h:85)
-//   7..9    direction of the pixel's primary ray (the same for every sample when the aperture is zero: the
+//   0..2    ray3D.srcN x,y,z (reference PathTracer.h:85)
+//   3..5    direction of the pixel's primary ray (the same for every sample when the aperture is zero: the
 //           reference samples pixel centres, PathTracer.c:625-628)
-//   10..    colours of finished paths waiting to be folded into the accumulator, in sample order: three per
-//           path, up to LS_PENDING_MAX paths (the render kernel picks its own ring length per variant)
 // Int slots:
 //   0..9    ray3D.r_index[0..9] (reference PathTracer.h:88), held as the index of the object whose r_index
 //           was pushed (RI_ONE: the initial 1.0 of initRay; RI_ZERO: never written)
-// 19 double + 10 int slots = 12 KiB per wave (twelve waves per CU); 13 + 10 slots = 9 KiB with a ring of one
-// (sixteen waves per CU).
-enum { LS_ACC = 0, LS_SRCN = 4, LS_PRIMARY_D = 7, LS_PENDING = 10, LS_PENDING_MAX = 3, LS_DSLOTS = LS_PENDING + 3 * LS_PENDING_MAX };
+// 6 double + 10 int slots = 5.5 KiB per wave.
+enum { LS_SRCN = 0, LS_PRIMARY_D = 3, LS_DSLOTS = 6 };
 enum { LS_RINDEX = 0, LS_ISLOTS = 10 };
 enum { RI_ONE = -1, RI_ZERO = -2 };
 struct LaneStore {

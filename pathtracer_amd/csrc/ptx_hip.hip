@@ -25,107 +25,95 @@
 #include "ptx_hip.h"
 #include "ptx_internal.h"
 
-// Waves per SIMD the render kernel is compiled for, and the length of a lane's ring of finished colours.  The
-// kernel for small scenes with a zero aperture (the benchmark case) needs about 144 registers: held to 128 it
-// spills 68 bytes per lane and runs four waves per SIMD, which is 5 % faster, provided the lane store shrinks to
-// 9 KiB per wave (a ring of one) so that sixteen waves fit a compute unit's LDS.  The variants with a hierarchy
-// or a lens need more registers and lose 10 % that way: three waves, a ring of three.
+// ------------------------------------------------------------------ kernels
+// Rendering is two kernels.  The reference folds each finished path into its pixel's accumulator with a
+// non-linear, order-dependent step (rgb += col * pow(2, -log(wt)); wt += R + G + B, PathTracer.c:646-652), so the
+// samples of a pixel must be folded in sample order -- but they can be traced in any order.  k_trace_samples traces
+// paths and writes each path's colour to a sample buffer in global memory, [pixel][sample] records of 32 bytes
+// (r, g, b, 0), so that a lane fills one cache line after another with its pixel's consecutive samples;
+// k_fold_samples then walks every pixel's samples in order, a line at a time.  That leaves the hot kernel free of the fold (a log and
+// a power per sample, which only the lanes that have just finished a path would execute) and free to cut the work
+// into as many waves as the GPU needs: a wave traces samples ks..ke of an 8x8 pixel tile, whatever the image size
+// or the share of it this GPU holds.  The buffer costs 32 bytes written and read per path, against ~6000 vector
+// instructions traced.
+#define PTX_SAMPLE_DOUBLES 4
+
+// Waves per SIMD the trace kernel is compiled for.  The kernel for small scenes with a zero aperture (the benchmark
+// case) is held to 128 registers, a little below what it wants, and runs four waves per SIMD; the variants with a
+// hierarchy or a lens need more registers and lose 10 % that way: three waves.
 template <bool USE_BVH, bool PINHOLE>
-struct RenderShape {
+struct TraceShape {
     static constexpr int waves_per_simd = (USE_BVH || !PINHOLE) ? 3 : 4;
-    static constexpr int pending_max = (USE_BVH || !PINHOLE) ? 3 : 1;
 };
 
-// ------------------------------------------------------------------ kernels
+// One lane per pixel of the tile; a lane starts its pixel's next sample as soon as its path ends (path
+// regeneration), so the wave stays full until its slowest pixel is done with the range.
 // PINHOLE: the aperture is zero, so every sample of a pixel starts along the same direction.
+// samples: colours of samples k0..k1-1 of this rank's pixels, `stride` records per pixel; sub_len: samples per
+// wave, a multiple of four.
 template <int FLAGS, bool USE_BVH, bool PINHOLE>
-__global__ void __launch_bounds__(PTX_BLOCK, (RenderShape<USE_BVH, PINHOLE>::waves_per_simd))
-    k_render(DevScene sc, DevRender rp, int k0, int k1, double *__restrict__ rgb, double *__restrict__ wght,
-             unsigned long long *__restrict__ stats) {
-    constexpr int PENDING_MAX = RenderShape<USE_BVH, PINHOLE>::pending_max;
-    __shared__ double lds_d_[LS_PENDING + 3 * PENDING_MAX][PTX_BLOCK];
+__global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::waves_per_simd))
+    k_trace_samples(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, size_t stride,
+                    double *__restrict__ samples, unsigned long long *__restrict__ stats) {
+    enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
+    __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
     const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (PTX_BLOCK >> 6) + (threadIdx.x >> 6);
+    const int tile = blockIdx.x % n_tiles, sub = blockIdx.x / n_tiles;
     const int tiles_x = (rp.sx + 7) >> 3;
-    const int tx = wave % tiles_x, ty = wave / tiles_x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int i = tx * 8 + (lane & 7);
     const int jl = ty * 8 + (lane >> 3);
     const bool inside = i < rp.sx && jl < rp.rows_owned;
     const int j = inside ? ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows) : 0;
     const size_t pix = inside ? (size_t)jl * rp.sx + i : 0;
+    const int ks = k0 + sub * sub_len;
+    const int ke = inside ? (ks + sub_len < k1 ? ks + sub_len : k1) : ks;
 
-    if (inside) {
-        ls.put(LS_ACC + 0, rgb[pix * 3 + 0]);
-        ls.put(LS_ACC + 1, rgb[pix * 3 + 1]);
-        ls.put(LS_ACC + 2, rgb[pix * 3 + 2]);
-        ls.put(LS_ACC + 3, wght[pix]);
-    }
     Counters cnt = {0, 0, 0};
     uint32_t paths = 0;
     Path ps;
     bool alive = false;
-    int k = inside ? k0 : k1;
-    constexpr bool cache_primary = PINHOLE;
-    if (cache_primary && inside) {
-        primary_ray(sc, rp, ls, i, j, k0, ps);
+    int k = ks;
+    if (PINHOLE && inside) {
+        primary_ray(sc, rp, ls, i, j, ks, ps);
         ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
     }
-    // Finished paths are folded into the accumulator in batches: a lane parks the colour of each finished path
-    // (at most PENDING_MAX of them), and when any lane of the wave has filled its slots every lane folds what it
-    // has, in sample order.  The fold (a log and an exp2 per sample) then runs with most lanes active instead of
-    // the quarter that finish in any one iteration.
-    int pending = 0;
     for (;;) {
         bool ended = false;
-        if (!alive && k < k1) {
-            if (cache_primary) primary_ray_cached(sc, rp, ls, i, j, k, ps);
+        if (!alive && k < ke) {
+            if (PINHOLE) primary_ray_cached(sc, rp, ls, i, j, k, ps);
             else primary_ray(sc, rp, ls, i, j, k, ps);
             alive = true;
             ended = rp.max_depth < 1;  // reference PathTracer.c:273 with depth = 1
         }
-        const bool any_alive = __ballot(alive) != 0ULL;
-        if (!any_alive || __ballot(pending == PENDING_MAX) != 0ULL) {
-            // fold, reference PathTracer.c:646-652
-            if (pending > 0) {
-                double ar = ls.get(LS_ACC + 0), ag = ls.get(LS_ACC + 1), ab = ls.get(LS_ACC + 2), wt = ls.get(LS_ACC + 3);
-                for (int q = 0; q < pending; q++) {
-                    double cr = ls.get(LS_PENDING + 3 * q), cg = ls.get(LS_PENDING + 3 * q + 1),
-                           cb = ls.get(LS_PENDING + 3 * q + 2);
-                    double f = exp2(-lean_log(wt));
-                    ar += cr * f;
-                    ag += cg * f;
-                    ab += cb * f;
-                    wt += cr;
-                    wt += cg;
-                    wt += cb;
-                }
-                ls.put(LS_ACC + 0, ar); ls.put(LS_ACC + 1, ag); ls.put(LS_ACC + 2, ab); ls.put(LS_ACC + 3, wt);
-                pending = 0;
-            }
-        }
-        if (!any_alive) break;
+        if (__ballot(alive) == 0ULL) break;
         double glossy = 0;
         if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true>(sc, rp, ls, ps, cnt, glossy);
         glossy_service(ps, glossy, lane);
-        if (alive) {
-            if (ended) {
-                ls.put(LS_PENDING + 3 * pending, ps.I.x);
-                ls.put(LS_PENDING + 3 * pending + 1, ps.I.y);
-                ls.put(LS_PENDING + 3 * pending + 2, ps.I.z);
-                pending++;
-                alive = false;
-                k++;
-                paths++;
+        if (alive && ended) {
+            // Four samples make a 128-byte line of the lane's stream.  The first three wait in LDS; the fourth goes
+            // out together with them, so that every line is written once and whole (sub_len and the stride are
+            // multiples of four, so lines start at k - ks = 0, 4, ...).  The last samples of a range go out singly.
+            const int slot = (k - ks) & 3;
+            double4 *out = (double4 *)(samples + (pix * stride + (size_t)(k - k0)) * PTX_SAMPLE_DOUBLES);
+            if (slot == 3) {
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    out[q - 3] = make_double4(ls.get(LS_PARKED + 3 * q), ls.get(LS_PARKED + 3 * q + 1), ls.get(LS_PARKED + 3 * q + 2), 0.0);
+                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
+            } else if (k + (3 - slot) >= ke) {
+                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
+            } else {
+                ls.put(LS_PARKED + 3 * slot, ps.I.x);
+                ls.put(LS_PARKED + 3 * slot + 1, ps.I.y);
+                ls.put(LS_PARKED + 3 * slot + 2, ps.I.z);
             }
+            alive = false;
+            k++;
+            paths++;
         }
-    }
-    if (inside) {
-        rgb[pix * 3 + 0] = ls.get(LS_ACC + 0);
-        rgb[pix * 3 + 1] = ls.get(LS_ACC + 1);
-        rgb[pix * 3 + 2] = ls.get(LS_ACC + 2);
-        wght[pix] = ls.get(LS_ACC + 3);
     }
     // one set of atomics per wave
     unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
@@ -141,6 +129,43 @@ __global__ void __launch_bounds__(PTX_BLOCK, (RenderShape<USE_BVH, PINHOLE>::wav
         atomicAdd(&stats[2], c2);
         if (c3) atomicAdd(&stats[3], c3);
     }
+}
+
+// One sample folded into a pixel's accumulator (reference PathTracer.c:646-652)
+__device__ __forceinline__ void fold_sample(double &ar, double &ag, double &ab, double &wt, double cr, double cg, double cb) {
+    const double f = exp2(-lean_log(wt));
+    ar += cr * f;
+    ag += cg * f;
+    ab += cb * f;
+    wt += cr;
+    wt += cg;
+    wt += cb;
+}
+
+// The accumulation for n_samples samples of every pixel, in sample order; one lane per pixel, four samples (one
+// 128-byte line of the lane's own stream) per trip.
+__global__ void __launch_bounds__(256) k_fold_samples(const double *__restrict__ samples, size_t n_pix, size_t stride,
+                                                       int n_samples, double *__restrict__ rgb, double *__restrict__ wght) {
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= n_pix) return;
+    double ar = rgb[pix * 3 + 0], ag = rgb[pix * 3 + 1], ab = rgb[pix * 3 + 2], wt = wght[pix];
+    const double4 *in = (const double4 *)(samples + pix * stride * PTX_SAMPLE_DOUBLES);
+    int q = 0;
+    for (; q + 4 <= n_samples; q += 4) {
+        const double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
+        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
+        fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
+        fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
+        fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
+    }
+    for (; q < n_samples; q++) {
+        const double4 s0 = in[q];
+        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
+    }
+    rgb[pix * 3 + 0] = ar;
+    rgb[pix * 3 + 1] = ag;
+    rgb[pix * 3 + 2] = ab;
+    wght[pix] = wt;
 }
 
 template <int FLAGS, bool USE_BVH>
@@ -250,8 +275,13 @@ struct ptx_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the last ptx_render_passes
+    std::vector<hipEvent_t> trace_ev;         // pairs around each k_trace_samples launch of that call
+    int n_trace_launches = 0;
     bool have_timing = false;
+    int n_cus = 256;                 // compute units of the device
+    double *d_samples = nullptr;     // sample buffer of the render kernels, grown on demand
+    size_t samples_bytes = 0;
     // scene
     bool have_scene = false;
     DevScene sc{};
@@ -293,6 +323,7 @@ extern "C" int ptx_init(int device, ptx_context **out) {
     HIPCHK(hipSetDevice(device));
     ptx_context *c = new ptx_context();
     c->device = device;
+    HIPCHK(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(hipEventCreate(&c->ev0));
@@ -310,6 +341,8 @@ extern "C" void ptx_shutdown(ptx_context *c) {
     free_render(c);
     free_scene(c);
     (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_samples);
+    for (hipEvent_t e : c->trace_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -594,6 +627,19 @@ static void dispatch_flags(int flags, bool use_bvh, F &&f) {
     });
 }
 
+// Largest sample buffer ptx_render_passes allocates: 32 GiB (PTX_SAMPLE_BUFFER_MB overrides), and never more than
+// half of what the device has free.  A call with more samples than fit is carried out in several rounds.
+static size_t sample_buffer_cap(size_t already_ours) {
+    size_t cap = (size_t)32 << 30;
+    if (const char *e = getenv("PTX_SAMPLE_BUFFER_MB")) {
+        const long long mb = atoll(e);
+        if (mb > 0) cap = (size_t)mb << 20;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, (free_b + already_ours) / 2);
+    return cap;
+}
+
 extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     if (!c) return fail(PTX_EINVAL, "null context");
     if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
@@ -601,21 +647,60 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     if (nk == 0 || c->rp.rows_owned == 0) return PTX_OK;
     HIPCHK(hipSetDevice(c->device));
     const int tiles_x = (c->rp.sx + 7) / 8, tiles_y = (c->rp.rows_owned + 7) / 8;
-    const long waves = (long)tiles_x * tiles_y;
-    const long waves_per_block = PTX_BLOCK / 64;
-    const unsigned blocks = (unsigned)((waves + waves_per_block - 1) / waves_per_block);
+    const long n_tiles = (long)tiles_x * tiles_y;
+    const size_t n_pix = (size_t)c->rp.rows_owned * c->rp.sx;
+    const size_t bytes_per_pass = n_pix * PTX_SAMPLE_DOUBLES * sizeof(double);  // of four passes at a time: see stride
+    // samples per round: what the buffer may hold
+    const size_t cap = sample_buffer_cap(c->samples_bytes);
+    // a pixel's records start on a 128-byte line: the stride is a multiple of four records
+    const int round_max = (int)std::max<size_t>(4, std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (cap / bytes_per_pass) & ~(size_t)3));
+    if ((size_t)round_max * bytes_per_pass > c->samples_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_samples);
+        c->d_samples = nullptr;
+        c->samples_bytes = 0;
+        HIPCHK(hipMalloc((void **)&c->d_samples, (size_t)round_max * bytes_per_pass));
+        c->samples_bytes = (size_t)round_max * bytes_per_pass;
+    }
+    const bool pinhole = c->rp.aperture == 0;
+    const long slots = (long)c->n_cus * 4 * ((c->use_bvh || !pinhole) ? 3 : 4);  // waves the GPU holds at once
+    // waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and
+    // short enough runs that a slow tile does not hold the end of the launch (measured best between 16 and 32)
+    long fill = 16;
+    if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
+    c->n_trace_launches = 0;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
-        constexpr int F = decltype(fl)::value;
-        constexpr bool B = decltype(bv)::value;
-        if (c->rp.aperture == 0)
-            hipLaunchKernelGGL((k_render<F, B, true>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk,
-                               c->d_rgb, c->d_wght, c->d_stats);
-        else
-            hipLaunchKernelGGL((k_render<F, B, false>), dim3(blocks), dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, k0, k0 + nk,
-                               c->d_rgb, c->d_wght, c->d_stats);
-    });
-    HIPCHK(hipGetLastError());
+    for (int ka = k0; ka < k0 + nk; ka += round_max) {
+        const int nka = std::min(round_max, k0 + nk - ka);
+        // a wave traces sub_len samples of a tile: as long a run as leaves enough waves, and at least 8
+        long n_sub = std::max(1L, std::min((fill * slots + n_tiles - 1) / n_tiles, (long)nka / 8));
+        const int sub_len = (int)(((nka + n_sub - 1) / n_sub + 3) & ~3L);
+        n_sub = (nka + sub_len - 1) / sub_len;
+        if (n_tiles * n_sub > 0x7fffffffL) return fail(PTX_EINVAL, "ptx_render_passes: image too large for one launch");
+        while ((int)c->trace_ev.size() < 2 * (c->n_trace_launches + 1)) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            c->trace_ev.push_back(e);
+        }
+        HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches], c->stream));
+        dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
+            constexpr int F = decltype(fl)::value;
+            constexpr bool B = decltype(bv)::value;
+            const dim3 grid((unsigned)(n_tiles * n_sub));
+            if (pinhole)
+                hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
+                                   sub_len, (int)n_tiles, (size_t)round_max, c->d_samples, c->d_stats);
+            else
+                hipLaunchKernelGGL((k_trace_samples<F, B, false>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
+                                   sub_len, (int)n_tiles, (size_t)round_max, c->d_samples, c->d_stats);
+        });
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches + 1], c->stream));
+        c->n_trace_launches++;
+        hipLaunchKernelGGL(k_fold_samples, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, c->stream, c->d_samples, n_pix, (size_t)round_max, nka,
+                           c->d_rgb, c->d_wght);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     c->have_timing = true;
     return PTX_OK;
@@ -633,6 +718,21 @@ extern "C" int ptx_last_pass_ms(ptx_context *c, float *ms) {
     if (!c->have_timing) return fail(PTX_ESTATE, "no pass has been launched");
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PTX_OK;
+}
+
+extern "C" int ptx_last_trace_ms(ptx_context *c, float *ms, int *launches) {
+    if (!c || !ms) return fail(PTX_EINVAL, "null argument");
+    if (!c->have_timing) return fail(PTX_ESTATE, "no pass has been launched");
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float total = 0;
+    for (int q = 0; q < c->n_trace_launches; q++) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, c->trace_ev[2 * q], c->trace_ev[2 * q + 1]));
+        total += t;
+    }
+    *ms = total;
+    if (launches) *launches = c->n_trace_launches;
     return PTX_OK;
 }
 

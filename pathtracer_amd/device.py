@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libp
 EXPORTS = [
     "ptx_init", "ptx_shutdown", "ptx_scene_upload", "ptx_render_begin", "ptx_render_begin_external",
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
-    "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
+    "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_last_trace_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
     "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload",
 ]
 
@@ -54,6 +54,7 @@ def load_library(path=None):
     lib.ptx_trace_paths.argtypes = [vp, C.POINTER(abi.RenderParams), vp, vp, vp, C.c_int64, vp]
     lib.ptx_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     lib.ptx_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ptx_last_trace_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ptx_set_stream.argtypes = [vp, vp]
     lib.ptx_selftest.argtypes = [vp, dp]
     lib.ptx_tonemap.argtypes = [vp, vp, C.POINTER(abi.TonemapInfo)]
@@ -177,3 +178,9 @@ class Device:
         ms = C.c_float()
         self._check(self.lib.ptx_last_pass_ms(self.ctx, C.byref(ms)))
         return ms.value
+
+    def last_trace_ms(self):
+        """(milliseconds in the path-tracing kernel during the last render_passes call, number of its launches)"""
+        ms, n = C.c_float(), C.c_int()
+        self._check(self.lib.ptx_last_trace_ms(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

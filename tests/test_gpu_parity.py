@@ -237,6 +237,32 @@ def test_hierarchy_order_does_not_change_results(name, scenes, monkeypatch):
     assert a[3]["paths"] == b[3]["paths"] and a[3]["closest_hits"] == b[3]["closest_hits"]
 
 
+def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
+    """A render_passes call traces its samples in as many rounds as the sample buffer needs and cuts each round
+    into waves of whatever length fills the GPU; the accumulator is folded in sample order all the same, so the
+    image does not depend on either choice, bit for bit."""
+    dev = gpu["cornell"]
+    sx, spp = 72, 40
+    prm = pt.make_params(sx, 6, ALL, 0.0, seed=12)
+    got = []
+    for buffer_mb, waves_per_slot in ((None, None), ("1", None), (None, "1"), ("1", "64")):
+        if buffer_mb is None:
+            monkeypatch.delenv("PTX_SAMPLE_BUFFER_MB", raising=False)
+        else:
+            monkeypatch.setenv("PTX_SAMPLE_BUFFER_MB", buffer_mb)  # 1 MiB: 6 samples of 72 x 72 pixels, four to a round
+        if waves_per_slot is None:
+            monkeypatch.delenv("PTX_WAVES_PER_SLOT", raising=False)
+        else:
+            monkeypatch.setenv("PTX_WAVES_PER_SLOT", waves_per_slot)
+        dev.render_begin(prm)
+        dev.render_passes(0, spp)
+        rgb, w = dev.download()
+        got.append((rgb, w, dev.stats(), dev.last_trace_ms()[1]))
+    assert got[1][3] == 10 and got[0][3] == 1  # launches of the tracing kernel: ten rounds of four samples, one round
+    for rgb, w, st, _ in got[1:]:
+        assert np.array_equal(rgb, got[0][0]) and np.array_equal(w, got[0][1]) and st == got[0][2]
+
+
 def test_render_resumed_from_saved_accumulators(gpu):
     """ptx_upload: passes 0..5 in one go equal passes 0..2, download, a fresh render_begin, upload, passes 3..5;
     with two ranks' row bands as well."""

@@ -24,6 +24,6 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ
   timeout -s KILL 180 rocprofv3 --pmc $C --output-format csv -d "$OUT/p$i" -- \
       python3 "$ROOT/tools/run_config.py" "$SCENE" "$SIZE" 25 > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; exit 1; }
 done
-python3 "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/pmc.json"
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$SCENE $SIZE" > "$OUT/pmc.json"
 cat "$OUT/run.log" | tail -2
 cat "$OUT/pmc.json"

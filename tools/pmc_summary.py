@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Sums the rocprofv3 counter CSVs of tools/collect_profiles.sh for the render kernel and prints one JSON object.
+"""Sums the rocprofv3 counter CSVs of tools/collect_profiles.sh for the path-tracing kernel and prints one JSON
+object.  usage: pmc_summary.py <directory with p*/ passes> [workload label, default "bench"]
 
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte read request as 64 bytes for wide
 streaming reads; the kernel's accumulator reads are 8 bytes per lane, a width for which the counter is not
-calibrated, so both the raw and the doubled figure are given."""
+calibrated, so both the raw and the doubled figure are given.  The kernel's reads are scene records and its own
+spilled registers; its writes are the traced samples (24 bytes per path) and spills."""
 import collections
 import csv
 import glob
@@ -16,12 +18,12 @@ launches = collections.defaultdict(int)
 for f in glob.glob(f"{d}/p*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        if "k_render" in r["Kernel_Name"]:
+        if "k_trace_samples" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             seen.add(r["Dispatch_Id"])
-    for c in {r["Counter_Name"] for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"]}:
+    for c in {r["Counter_Name"] for r in csv.DictReader(open(f)) if "k_trace_samples" in r["Kernel_Name"]}:
         launches[c] = max(launches[c], len(seen))
-out = {"kernel": "k_render", "launches_per_run": max(launches.values()) if launches else 0,
+out = {"kernel": "k_trace_samples", "workload": sys.argv[2] if len(sys.argv) > 2 else "bench", "launches_per_run": max(launches.values()) if launches else 0,
        "counters": {k: tot[k] for k in sorted(tot)}}
 n = max(1, out["launches_per_run"])
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
