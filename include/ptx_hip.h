@@ -76,7 +76,12 @@ int ptx_render_begin_external(ptx_context *ctx, const ptx_render_params *params,
 /* Runs passes k0 .. k0+nk-1 of the sample loop for every pixel this rank
  * owns: primary ray, PathTrace, and the ordered fold into the accumulator
  * (PathTracer.c:617-654 without the dataOutput call at :655).  Returns
- * once the work is queued on the context's stream. */
+ * once the work is queued on the context's stream.  The paths are traced
+ * first, their colours going to a buffer in device memory (32 bytes per
+ * pixel and pass, allocated by the first call that needs it, kept until
+ * ptx_shutdown, at most 32 GiB and half of the free memory), and folded
+ * into the accumulators in pass order afterwards; a call too large for the
+ * buffer is carried out in several rounds, with the same result. */
 int ptx_render_passes(ptx_context *ctx, int k0, int nk);
 
 /* Waits for queued work (the reference's loop is synchronous). */
