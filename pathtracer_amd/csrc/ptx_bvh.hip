@@ -168,6 +168,9 @@ __device__ inline int preorder_of(int node_is_leaf, int idx, int o, const int *l
     return pos;
 }
 
+// x as a float that is not above it (a lower bound) or not below it (an upper bound)
+__device__ inline float outward(double x, int upper) { return upper ? __double2float_ru(x) : __double2float_rd(x); }
+
 __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__ ids, const int *__restrict__ prim_ids, int n,
                        int o, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
                        const int *__restrict__ parent_leaf, const int *__restrict__ first, const int *__restrict__ last,
@@ -179,18 +182,17 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
     int pre;
     if (t < n - 1) {  // inner node t
         pre = preorder_of(0, t, o, left, right, parent_inner, parent_leaf, first, last, order);
-        for (int q = 0; q < 6; q++) node.box[q] = inner_box[6 * (size_t)t + q];
+        for (int q = 0; q < 6; q++) node.box[q] = outward(inner_box[6 * (size_t)t + q], q & 1);
         node.obj = -1;
         node.skip = pre + 2 * (last[t] - first[t] + 1) - 1;
     } else {  // leaf at sorted position i
         int i = t - (n - 1);
         pre = n == 1 ? 0 : preorder_of(1, i, o, left, right, parent_inner, parent_leaf, first, last, order);
         const double *b = boxes + 6 * (size_t)ids[i];
-        for (int q = 0; q < 6; q++) node.box[q] = b[q];
+        for (int q = 0; q < 6; q++) node.box[q] = outward(b[q], q & 1);
         node.obj = prim_ids[ids[i]];
         node.skip = pre + 1;
     }
-    node.pad = 0;
     out[pre] = node;
 }
 

@@ -420,10 +420,10 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         const int octant = sc.bvh_per_octant ? ((d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2) : 0;
         const PtxBvhNode *nodes = sc.bvh + (size_t)octant * (size_t)n_nodes;
         while (node < n_nodes) {
-            const PtxBvhNode &nd = nodes[node];
-            double t0 = (nd.box[0] - p0.x) * ix, t1 = (nd.box[1] - p0.x) * ix;
-            double t2 = (nd.box[2] - p0.y) * iy, t3 = (nd.box[3] - p0.y) * iy;
-            double t4 = (nd.box[4] - p0.z) * iz, t5 = (nd.box[5] - p0.z) * iz;
+            const PtxBvhNode nd = nodes[node];
+            double t0 = ((double)nd.box[0] - p0.x) * ix, t1 = ((double)nd.box[1] - p0.x) * ix;
+            double t2 = ((double)nd.box[2] - p0.y) * iy, t3 = ((double)nd.box[3] - p0.y) * iy;
+            double t4 = ((double)nd.box[4] - p0.z) * iz, t5 = ((double)nd.box[5] - p0.z) * iz;
             double lmin = fmax(fmax(fmin(t0, t1), fmin(t2, t3)), fmin(t4, t5));
             double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
             double slack = 1e-12 * (fabs(lmin) + fabs(lmax));

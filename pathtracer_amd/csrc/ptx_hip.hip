@@ -491,7 +491,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     for (size_t q = 0; q < list_ids.size(); q++) list_geom[q] = geom[list_ids[q]];
     PtxBvhNode *d_bvh = nullptr;
     int n_bvh_nodes = 0;
-    // One node array per octant of ray directions (1 KiB per primitive in all; +56 % on the 8000-cube sponge and
+    // One node array per octant of ray directions (512 bytes per primitive in all; +56 % on the 8000-cube sponge and
     // +23 % on a million triangles over a single array), a single array beyond 16 M primitives.
     // PTX_BVH_ORDERS=1 or 8 overrides the choice (for measurements).
     int bvh_orders = bvh_ids.size() <= (16u << 20) ? 8 : 1;
