@@ -8,9 +8,10 @@
 
 // Nodes are stored in depth-first order.  Walking the array needs no stack: after a node whose box the ray
 // enters comes the next entry; after a node it misses, or a leaf, comes entry `skip`.
-// The box is held in single precision, every lower bound rounded down and every upper bound rounded up, so it
-// contains the double-precision box of the scene description: a ray that enters the latter enters the former, and
-// the primitive test, not the box, decides about a hit.  32 bytes a node: two 16-byte loads per step, and the eight
+// The box is held in single precision, every bound moved outward by a millionth of the scene's size and then
+// rounded outward, so it contains the double-precision box of the scene description with room to spare: a ray
+// that enters the latter enters the former however the walk rounds its slab test, and the primitive test, not
+// the box, decides about a hit.  32 bytes a node: two 16-byte loads per step, and the eight
 // arrays of a scene of 8000 primitives (4 MB) stay within one L2.
 struct PtxBvhNode {
     float box[6];  // xl xu yl yu zl zu, world space

@@ -168,11 +168,13 @@ __device__ inline int preorder_of(int node_is_leaf, int idx, int o, const int *l
     return pos;
 }
 
-// x as a float that is not above it (a lower bound) or not below it (an upper bound)
-__device__ inline float outward(double x, int upper) { return upper ? __double2float_ru(x) : __double2float_rd(x); }
+// x moved outward by `margin` as a float that is not above it (a lower bound) or not below it (an upper bound)
+__device__ inline float outward(double x, int upper, double margin) {
+    return upper ? __double2float_ru(x + margin) : __double2float_rd(x - margin);
+}
 
 __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__ ids, const int *__restrict__ prim_ids, int n,
-                       int o, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
+                       int o, double margin, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
                        const int *__restrict__ parent_leaf, const int *__restrict__ first, const int *__restrict__ last,
                        const unsigned char *__restrict__ order, const double *__restrict__ inner_box,
                        PtxBvhNode *__restrict__ out) {
@@ -182,14 +184,14 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
     int pre;
     if (t < n - 1) {  // inner node t
         pre = preorder_of(0, t, o, left, right, parent_inner, parent_leaf, first, last, order);
-        for (int q = 0; q < 6; q++) node.box[q] = outward(inner_box[6 * (size_t)t + q], q & 1);
+        for (int q = 0; q < 6; q++) node.box[q] = outward(inner_box[6 * (size_t)t + q], q & 1, margin);
         node.obj = -1;
         node.skip = pre + 2 * (last[t] - first[t] + 1) - 1;
     } else {  // leaf at sorted position i
         int i = t - (n - 1);
         pre = n == 1 ? 0 : preorder_of(1, i, o, left, right, parent_inner, parent_leaf, first, last, order);
         const double *b = boxes + 6 * (size_t)ids[i];
-        for (int q = 0; q < 6; q++) node.box[q] = outward(b[q], q & 1);
+        for (int q = 0; q < 6; q++) node.box[q] = outward(b[q], q & 1, margin);
         node.obj = prim_ids[ids[i]];
         node.skip = pre + 1;
     }
@@ -225,6 +227,14 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
         }
     double sc[3];
     for (int a = 0; a < 3; a++) sc[a] = hi[a] > lo[a] ? 2097151.0 / (hi[a] - lo[a]) : 0.0;
+    // Node boxes are pushed outward by a millionth of the scene's size (the largest coordinate or extent): the
+    // walk tests them with a shorter, less exact form of the slab test and without a tolerance of its own, and
+    // a ray that starts on a primitive's surface must still find itself inside that primitive's box.
+    double scale = 0;
+    for (size_t q = 0; q < 6 * (size_t)n; q++)
+        if (std::isfinite(h_boxes[q])) scale = std::max(scale, std::fabs(h_boxes[q]));
+    for (int a = 0; a < 3; a++) scale = std::max(scale, hi[a] - lo[a]);
+    const double margin = scale * 0x1p-20;
 
     double *d_boxes = nullptr, *d_inner_box = nullptr;
     int *d_prim = nullptr, *d_ids = nullptr, *d_ids2 = nullptr, *d_left = nullptr, *d_right = nullptr, *d_pin = nullptr,
@@ -277,7 +287,7 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
         BVHCHK(hipGetLastError());
     }
     for (int o = 0; o < n_orders; o++) {
-        hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, o, d_left, d_right, d_pin, d_pleaf,
+        hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, o, margin, d_left, d_right, d_pin, d_pleaf,
                            d_first, d_last, d_order, d_inner_box, d_nodes + (size_t)o * (2 * n - 1));
         BVHCHK(hipGetLastError());
     }

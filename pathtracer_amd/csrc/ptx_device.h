@@ -390,8 +390,8 @@ __device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double
 //    no lane diverges on the primitive type.
 //  - The hierarchy is walked per lane without a stack (PtxBvhNode::skip).  A node is entered if the ray's slab
 //    interval is not empty, does not end behind the origin and does not start beyond the best hit so far; the
-//    reference's box_intersect (magic.c:457-474) is the same slab test without the last condition.  A relative
-//    slack keeps rounding from rejecting a box the reference would enter.
+//    reference's box_intersect (magic.c:457-474) is the same slab test without the last condition.  The node
+//    boxes are a little larger than the reference's, which keeps rounding from rejecting one it would enter.
 template <bool USE_BVH>
 __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os) {
     Hit h;
@@ -413,7 +413,11 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         }
     }
     if (USE_BVH) {
+        // slab test as b * (1/d) - p0 * (1/d): one fused multiply-add per plane.  It is less exact than
+        // (b - p0) / d near b = p0, by far less than the margin the node boxes carry (ptx_bvh.h); for a direction
+        // component of zero both planes give NaN, which fmin/fmax ignore: the slab then never rejects.
         const double ix = rcp_or_inf(d.x), iy = rcp_or_inf(d.y), iz = rcp_or_inf(d.z);
+        const double ox = p0.x * ix, oy = p0.y * iy, oz = p0.z * iz;
         int node = 0;
         const int n_nodes = sc.n_bvh_nodes;
         // the array whose order suits this ray: nearer children first (ptx_bvh.h)
@@ -421,14 +425,13 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         const PtxBvhNode *nodes = sc.bvh + (size_t)octant * (size_t)n_nodes;
         while (node < n_nodes) {
             const PtxBvhNode nd = nodes[node];
-            double t0 = ((double)nd.box[0] - p0.x) * ix, t1 = ((double)nd.box[1] - p0.x) * ix;
-            double t2 = ((double)nd.box[2] - p0.y) * iy, t3 = ((double)nd.box[3] - p0.y) * iy;
-            double t4 = ((double)nd.box[4] - p0.z) * iz, t5 = ((double)nd.box[5] - p0.z) * iz;
+            double t0 = fma((double)nd.box[0], ix, -ox), t1 = fma((double)nd.box[1], ix, -ox);
+            double t2 = fma((double)nd.box[2], iy, -oy), t3 = fma((double)nd.box[3], iy, -oy);
+            double t4 = fma((double)nd.box[4], iz, -oz), t5 = fma((double)nd.box[5], iz, -oz);
             double lmin = fmax(fmax(fmin(t0, t1), fmin(t2, t3)), fmin(t4, t5));
             double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
-            double slack = 1e-12 * (fabs(lmin) + fabs(lmax));
             int next = nd.skip;
-            if (!(lmin > lmax + slack) && !(lmax < -slack) && !(lmin > h.lambda + slack)) {
+            if (!(lmin > lmax) && !(lmax < 0) && !(lmin > h.lambda)) {
                 const int id = nd.obj;
                 next = node + 1;
                 if (id >= 0 && id != os) {
