@@ -29,6 +29,19 @@ def local_row_count(sx, rank, world, band_rows):
     return abi.rows_owned(sx, rank, world, band_rows)
 
 
+_ROW_INDEX_CACHE = {}
+
+
+def _global_rows_tensor(sx, r, world, band_rows, device):
+    """Whole-image row numbers of rank r's rows as an index tensor on `device` (built once per split)."""
+    key = (sx, r, world, band_rows, str(device))
+    t = _ROW_INDEX_CACHE.get(key)
+    if t is None:
+        t = torch.as_tensor(abi.global_rows(sx, r, world, band_rows), device=device)
+        _ROW_INDEX_CACHE[key] = t
+    return t
+
+
 def gather_accumulators(rgb_local, wght_local, sx, rank, world, band_rows, dst=0, group=None):
     """Collects every rank's rows on `dst` and returns whole-image tensors there (None elsewhere).
 
@@ -50,7 +63,7 @@ def gather_accumulators(rgb_local, wght_local, sx, rank, world, band_rows, dst=0
     rgb = torch.empty(sx, sx, 3, dtype=torch.float64, device=rgb_local.device)
     wght = torch.empty(sx, sx, dtype=torch.float64, device=rgb_local.device)
     for r in range(world):
-        rows = torch.as_tensor(abi.global_rows(sx, r, world, band_rows), device=rgb_local.device)
+        rows = _global_rows_tensor(sx, r, world, band_rows, rgb_local.device)
         rgb[rows] = bufs[r][: counts[r], :, :3]
         wght[rows] = bufs[r][: counts[r], :, 3]
     return rgb, wght
