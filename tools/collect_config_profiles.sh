@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiles of the render kernel on one of the larger configurations (a hierarchy scene), on a GPU box:
+# Profiles of the path-tracing kernel on one of the larger configurations (a hierarchy scene), on a GPU box:
 #   tools/collect_config_profiles.sh <tag> scifi|bubbletea [size]
 # 1. rocprofv3 --kernel-trace --stats over 50 passes (two 25-pass launches) -> gpurun_out/<tag>/kernel_stats.csv
 # 2. hardware counters of one 25-pass launch, one rocprofv3 run per counter set -> gpurun_out/<tag>/pmc.json
