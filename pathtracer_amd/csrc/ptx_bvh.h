@@ -16,12 +16,18 @@
 struct PtxBvhNode {
     float box[6];  // xl xu yl yu zl zu, world space
     int32_t skip;  // index of the first node after this node's subtree
-    int32_t obj;   // leaf: index of the primitive in the scene's object array; inner node: -1
+    int32_t obj;   // leaf: what the caller gave for the primitive (see PTX_LEAF_*); inner node: -1
 };
+// What the path tracer stores for a leaf: the primitive's index in the scene's object array, whether it is a
+// uniformly scaled sphere, and its type, so that a ray can pick the intersection routine before the record of the
+// primitive has arrived.
+#define PTX_LEAF_INDEX 0x07ffffff
+#define PTX_LEAF_FAST 0x08000000
+#define PTX_LEAF_TYPE_SHIFT 28
 static_assert(sizeof(PtxBvhNode) == 32, "PtxBvhNode layout");
 
 // Builds the hierarchy over n primitives given their world boxes (host memory, 6 doubles each) and the scene
-// object index of each.  n_orders is 1 (one array, left child first) or 8 (one array per octant of ray directions,
+// leaf value of each (non-negative).  n_orders is 1 (one array, left child first) or 8 (one array per octant of ray directions,
 // octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, nearer child first).  On success *d_nodes_out points to
 // n_orders arrays of *n_nodes_out = 2n-1 nodes each, back to back in device memory (caller frees with hipFree);
 // links are relative to the start of their own array.

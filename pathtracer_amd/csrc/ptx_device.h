@@ -371,17 +371,23 @@ struct Hit {
 // lambda of one primitive for one ray (dd = d.d, inv_dd = 1/dd)
 // g: pointer to the geometry record, in global memory (per lane) or, for the always-tested list, in the constant
 // address space (ConstGeomPtr)
+// type, fast: the record's own fields, passed in where the caller knows them without reading the record (a leaf of
+// the hierarchy carries them), so that the loads of the record do not wait for its type
 template <typename GP>
-__device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double inv_dd, int &part) {
+__device__ __forceinline__ double isect_typed(GP g, int type, int fast, V3 p0, V3 d, double dd, double inv_dd, int &part) {
     part = 0;
-    if (g->fast) return isect_sphere_uniform(g, p0, d, dd, inv_dd);
-    switch (g->type) {
+    if (fast) return isect_sphere_uniform(g, p0, d, dd, inv_dd);
+    switch (type) {
     case PTX_SPHERE: return isect_sphere(&g->m[0], p0, d);
     case PTX_PLANE: return isect_plane(&g->m[0], p0, d);
     case PTX_TRIANGLE: return isect_triangle(&g->m[0], p0, d, part);
     case PTX_CYL: return isect_cyl(&g->m[0], p0, d, part);
     default: return isect_box(&g->m[0], p0, d, part);  // PTX_CUBE, PTX_ROOM
     }
+}
+template <typename GP>
+__device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double inv_dd, int &part) {
+    return isect_typed(g, g->type, g->fast, p0, d, dd, inv_dd, part);
 }
 
 // findFirstHit (reference PathTracer.c:198-251): the smallest lambda > TOL wins and, between equal lambdas, the
@@ -432,11 +438,12 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
             double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
             int next = nd.skip;
             if (!(lmin > lmax) && !(lmax < 0) && !(lmin > h.lambda)) {
-                const int id = nd.obj;
+                const int leaf = nd.obj;
+                const int id = leaf & PTX_LEAF_INDEX;
                 next = node + 1;
-                if (id >= 0 && id != os) {
+                if (leaf >= 0 && id != os) {
                     int part;
-                    double lam = isect_any(&sc.geom[id], p0, d, dd, inv_dd, part);
+                    double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, dd, inv_dd, part);
                     if (lam > PT_TOL && (lam < h.lambda || (lam == h.lambda && id < h.obj))) {
                         h.lambda = lam;
                         h.obj = id;

@@ -500,7 +500,13 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         std::vector<double> boxes(6 * bvh_ids.size());
         for (size_t q = 0; q < bvh_ids.size(); q++) memcpy(&boxes[6 * q], s->objects[bvh_ids[q]].box, 48);
         std::string err;
-        if (ptx_bvh_build(boxes.data(), bvh_ids.data(), (int)bvh_ids.size(), bvh_orders, c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
+        if (n > PTX_LEAF_INDEX) return fail(PTX_EINVAL, "ptx_scene_upload: too many objects for the hierarchy's leaf encoding");
+        std::vector<int> leaves(bvh_ids.size());
+        for (size_t q = 0; q < bvh_ids.size(); q++) {
+            const DevGeom &g = geom[bvh_ids[q]];
+            leaves[q] = bvh_ids[q] | (g.fast ? PTX_LEAF_FAST : 0) | (g.type << PTX_LEAF_TYPE_SHIFT);
+        }
+        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
             return fail(PTX_EDEVICE, "ptx_scene_upload: hierarchy build failed: " + err);
     }
     c->d_bvh = d_bvh;
