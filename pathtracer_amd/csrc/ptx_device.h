@@ -560,15 +560,33 @@ __device__ __forceinline__ void tex_map(const DevScene &sc, int img, double a, d
     long n = (long)im.sx * im.sy * 3;
     const double inv = fast_rcp(im.divisor);
     double out[3];
+    if (x1 >= 0 && y1 >= 0 && x2 < im.sx && y2 < im.sy) {
+        // all four texels inside the image: the two of a row are six adjacent bytes, fetched with one load (the
+        // texel buffer ends in eight spare bytes)
+        uint64_t row1, row2;
+        __builtin_memcpy(&row1, sc.texels + im.offset + 3L * ((long)y1 * im.sx + x1), 8);
+        __builtin_memcpy(&row2, sc.texels + im.offset + 3L * ((long)y2 * im.sx + x1), 8);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        double c11 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x1) + c, n);
-        double c12 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x1) + c, n);
-        double c21 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x2) + c, n);
-        double c22 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x2) + c, n);
-        double avg1 = c11 * (x2 - x) + c21 * (x - x1);
-        double avg2 = c12 * (x2 - x) + c22 * (x - x1);
-        out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
+        for (int c = 0; c < 3; c++) {
+            double c11 = texel_value((double)(uint32_t)((row1 >> (8 * c)) & 255), im.divisor, inv);
+            double c21 = texel_value((double)(uint32_t)((row1 >> (8 * c + 24)) & 255), im.divisor, inv);
+            double c12 = texel_value((double)(uint32_t)((row2 >> (8 * c)) & 255), im.divisor, inv);
+            double c22 = texel_value((double)(uint32_t)((row2 >> (8 * c + 24)) & 255), im.divisor, inv);
+            double avg1 = c11 * (x2 - x) + c21 * (x - x1);
+            double avg2 = c12 * (x2 - x) + c22 * (x - x1);
+            out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double c11 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x1) + c, n);
+            double c12 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x1) + c, n);
+            double c21 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x2) + c, n);
+            double c22 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x2) + c, n);
+            double avg1 = c11 * (x2 - x) + c21 * (x - x1);
+            double avg2 = c12 * (x2 - x) + c22 * (x - x1);
+            out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
+        }
     }
     R = out[0];
     G = out[1];

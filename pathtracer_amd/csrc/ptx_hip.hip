@@ -520,7 +520,8 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     HIPCHK(hipMalloc(&c->d_mat, mat.size() * sizeof(DevMat)));
     HIPCHK(hipMalloc(&c->d_lights, lights.size() * sizeof(DevLight)));
     HIPCHK(hipMalloc(&c->d_images, images.size() * sizeof(DevImage)));
-    HIPCHK(hipMalloc(&c->d_texels, s->n_texel_bytes ? s->n_texel_bytes : 16));
+    HIPCHK(hipMalloc(&c->d_texels, s->n_texel_bytes + 16));  // spare bytes: a row's two texels are read as one 8-byte word
+    HIPCHK(hipMemset((char *)c->d_texels + s->n_texel_bytes, 0, 16));
     HIPCHK(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_mat, mat.data(), mat.size() * sizeof(DevMat), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
