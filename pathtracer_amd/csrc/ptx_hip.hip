@@ -476,11 +476,20 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         std::vector<int> order(n);
         for (int k = 0; k < n; k++) order[k] = k;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return extent[a] > extent[b]; });
+        // Direct: boxes more than 16 times the median (measured on SciFiCube and BubbleTea: smaller factors put
+        // BubbleTea's cards and bubbles on the list, which costs more than walking to them; larger ones send
+        // SciFiCube's pillars into the hierarchy, whose boxes most rays cross), and light sources of at least
+        // half that size, which every shadow ray heads for.
         std::vector<char> direct(n, 0);
-        for (int q = 0; q < n && q < MAX_DIRECT; q++) {
+        int n_direct = 0;
+        for (int q = 0; q < n && n_direct < MAX_DIRECT; q++) {
             int k = order[q];
-            if (!(extent[k] > 8.0 * median) && std::isfinite(extent[k])) break;
+            if (!std::isfinite(extent[k])) continue;
+            const double factor = s->objects[k].is_light ? 8.0 : 16.0;
+            if (!(extent[k] > 8.0 * median)) break;
+            if (!(extent[k] > factor * median)) continue;
             direct[k] = 1;
+            n_direct++;
         }
         for (int k = 0; k < n; k++) {
             if (!std::isfinite(extent[k])) direct[k] = 1;  // a box that is not finite cannot be sorted into a hierarchy
