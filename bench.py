@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--chunk", type=int, default=0, help="passes per kernel launch (0 = all of them in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="run the N-rank code path on however many GPUs there are (ranks share GPUs, gloo instead of "
+                         "RCCL): a check of the multi-rank plumbing, not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -122,12 +125,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be started through torch.distributed.run with N ranks")
+    if args.rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     torch.cuda.init()  # PyTorch's HIP runtime first, then the library's (they are separate copies of the runtime)
     torch.zeros(1, device=torch.device("cuda", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
     flags = pt.abi.USE_IS | pt.abi.USE_ES | pt.abi.USE_RR
@@ -172,7 +180,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stats = dev.stats()
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -204,7 +212,7 @@ def main():
             "workload": f"CornellBox {sx}x{sx}, depth {depth}, {spp} spp, IS=1 ES=1 RR=1, aperture 0",
             "passes_per_launch": chunk,
             "band_rows": band,
-            "parallelism": f"rows in bands over {world} GPU(s), gather to rank 0",
+            "parallelism": f"rows in bands over {world} GPU(s), gather to rank 0" + (" [rehearsal: shared GPUs, gloo]" if args.rehearse else ""),
         },
         "mrays_per_s": paths_per_s * rays_per_path / 1e6,
         "rays_per_path": rays_per_path,

@@ -56,8 +56,15 @@ def gather_accumulators(rgb_local, wght_local, sx, rank, world, band_rows, dst=0
     n = counts[rank]
     packed[:n, :, :3] = rgb_local.view(n, sx, 3)
     packed[:n, :, 3] = wght_local.view(n, sx)
-    bufs = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
-    dist.gather(packed, bufs, dst=dst, group=group)
+    if packed.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only (a rehearsal of the GPU path without RCCL)
+        staged = packed.cpu()
+        host_bufs = [torch.empty_like(staged) for _ in range(world)] if rank == dst else None
+        dist.gather(staged, host_bufs, dst=dst, group=group)
+        bufs = [b.to(packed.device) for b in host_bufs] if rank == dst else None
+    else:
+        bufs = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+        dist.gather(packed, bufs, dst=dst, group=group)
     if rank != dst:
         return None, None
     rgb = torch.empty(sx, sx, 3, dtype=torch.float64, device=rgb_local.device)
