@@ -20,6 +20,7 @@ sys.path.insert(0, REPO)
 # hit attributes) + 4.08 bounces x 120 FLOP (shading) + 10 (accumulate).
 FLOP_PER_PATH = 3.9e3
 PEAK_FP32_TFLOPS = 157.3
+PEAK_FP64_TFLOPS = 78.6
 
 
 def recorded_hbm_traffic(rows, sx):
@@ -98,7 +99,7 @@ def cpu_baseline(sx, depth, flags, seconds_target=15.0):
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -111,8 +112,24 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="run the N-rank code path on however many GPUs there are (ranks share GPUs, gloo instead of "
                          "RCCL): a check of the multi-rank plumbing, not a measurement")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
+    from pathtracer_amd import launch
+
+    if args.gpus > 1 and not launch.under_launcher():
+        # plain `python bench.py --gpus N`: this process starts the N ranks (it has not touched the GPU) and hands on
+        # rank 0's line.  Under torch.distributed.run the ranks exist already.
+        rc, out = launch.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        sys.exit(rc)
+    run(args)
+
+
+def run(args):
     import torch
     import torch.distributed as dist
 
@@ -123,12 +140,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be started through torch.distributed.run with N ranks")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     if args.rehearse:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    torch.cuda.init()  # PyTorch's HIP runtime first, then the library's (they are separate copies of the runtime)
+    torch.cuda.init()
     torch.zeros(1, device=torch.device("cuda", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,18 +160,23 @@ def main():
     band = parallel.band_rows_for(sx, world)
     scene = pt.Scene.from_file(os.path.join(REPO, "tests", "golden", "cornell.ptxscene"))
     dev = pt.Device(local_rank)
-    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    # The library launches on PyTorch's stream, so that the collective that follows is ordered after the render
+    # without a host synchronisation.  That is valid only if both use one copy of the HIP runtime; with two copies
+    # the library keeps its own stream and the step waits for it before the gather.
+    runtimes = parallel.hip_runtime_copies()
+    shared_stream = len(runtimes) == 1
+    if shared_stream:
+        dev.set_stream(torch.cuda.current_stream().cuda_stream)
     dev.scene_upload(scene)
     prm = pt.make_params(sx, depth, flags, 0.0, seed=2024, rank=rank, n_ranks=world, band_rows=band)
-    rows = parallel.local_row_count(sx, rank, world, band)
-    rgb = torch.zeros(rows * sx * 3, dtype=torch.float64, device=device)
-    wght = torch.ones(rows * sx, dtype=torch.float64, device=device)
+    gat = parallel.Gatherer(sx, rank, world, band, device)  # accumulators, receive buffers and the whole image, once
+    rows = gat.rows
     kernel_ms = []
+    gather_s = []
 
     def step(record):
-        rgb.zero_()
-        wght.fill_(1.0)
-        dev.render_begin(prm, rgb.data_ptr(), wght.data_ptr())
+        gat.reset()
+        dev.render_begin(prm, gat.rgb_local.data_ptr(), gat.wght_local.data_ptr())
         k = 0
         while k < spp:
             nk = min(chunk, spp - k)
@@ -163,7 +184,16 @@ def main():
             if record:
                 kernel_ms.append(dev.last_trace_ms() + (nk,))
             k += nk
-        return parallel.gather_accumulators(rgb, wght, sx, rank, world, band)
+        if not shared_stream:
+            dev.sync()
+        if record and world > 1:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = gat.gather()
+            torch.cuda.synchronize()
+            gather_s.append(time.perf_counter() - t)
+            return out
+        return gat.gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -194,7 +224,8 @@ def main():
     paths_launches = sum(rows * sx * nk for _, _, nk in kernel_ms)
     achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
     rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
-    traffic, traffic_src = recorded_hbm_traffic(rows, sx) if sx == 1024 else (None, None)
+    same_workload = sx == 1024 and spp == 1000 and chunk == spp and depth == 6
+    traffic, traffic_src = recorded_hbm_traffic(rows, sx) if same_workload else (None, None)
     out = {
         "metric": "paths/s (pixel-samples per second), Cornell box 1024^2 depth 6 IS+ES+RR",
         "value": paths_per_s,
@@ -213,28 +244,34 @@ def main():
             "passes_per_launch": chunk,
             "band_rows": band,
             "parallelism": f"rows in bands over {world} GPU(s), gather to rank 0" + (" [rehearsal: shared GPUs, gloo]" if args.rehearse else ""),
+            "hip_runtime_copies": runtimes,
         },
         "mrays_per_s": paths_per_s * rays_per_path / 1e6,
         "rays_per_path": rays_per_path,
+        "gather_ms_per_step": (sum(gather_s) / len(gather_s) * 1e3) if gather_s else 0.0,
         "roofline": {
             "bound": "valu",
             "achieved": achieved_tflops,
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+            "frac_of_fp64_vector_peak": achieved_tflops / PEAK_FP64_TFLOPS,
             "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic_source": None if traffic_src is None else f"recorded: profiles/{traffic_src} (same workload, counters of an earlier run)",
             "algorithmic_hbm_bytes_per_launch": 32 * paths_launches // max(1, n_launches),
             "kernel": "k_trace_samples",
             "kernel_ms_avg": ms_sum / max(1, n_launches),
             "flop_per_path_model": FLOP_PER_PATH,
-            "note": "vector FP32 peak (no MFMA: the work is not a dense contraction); arithmetic runs in FP64 "
-                    "(peak 78.6 TFLOP/s), so frac against the FP64 vector peak is twice this value",
+            "note": "achieved = paths x a MODEL of 3.9 kFLOP per path (not a counter) / kernel time; peak = vector FP32 "
+                    "(no MFMA: the work is not a dense contraction); the arithmetic runs in FP64, whose vector peak is "
+                    "78.6 TFLOP/s (frac_of_fp64_vector_peak); the FP64 operations the counters see are listed in "
+                    "profiles/*_pmc.json",
         },
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sx, depth, flags)
+            out["speedup_over_cpu_baseline"] = paths_per_s / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

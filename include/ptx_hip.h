@@ -144,6 +144,20 @@ int ptx_first_hit_device(ptx_context *ctx, const ptx_ray *d_rays, int64_t n, ptx
 int ptx_trace_paths(ptx_context *ctx, const ptx_render_params *params, const int32_t *pix_i, const int32_t *pix_j,
                     const int32_t *sample, int64_t n, double *out);
 
+/* What the closest-hit queries (PathTracer.c:282, :428) of the most recent ptx_trace_paths call tested: that entry
+ * point runs the instrumented build of the path kernel.  The reference counts nothing of the kind; these figures
+ * turn a scene into FLOP and bytes per ray (24 FLOP and 32 bytes per node visit, the per-type cost of each
+ * primitive test).  Synchronises. */
+typedef struct ptx_walk_stats {
+    uint64_t queries;        /* closest-hit + shadow queries */
+    uint64_t hits;           /* of which found a primitive */
+    uint64_t list_tests;     /* primitive tests on the always-tested list */
+    uint64_t node_visits;    /* hierarchy nodes whose box was tested (inner nodes and leaves) */
+    uint64_t leaf_tests[6];  /* primitive tests at leaves, by PTX_PLANE .. PTX_ROOM */
+    uint64_t texel_lookups;  /* texMap / normalDeform / alphaMap calls (four texels each) */
+} ptx_walk_stats;
+int ptx_last_walk_stats(ptx_context *ctx, ptx_walk_stats *stats);
+
 /* Counters accumulated since ptx_render_begin (synchronises). */
 int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);
 

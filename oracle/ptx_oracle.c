@@ -932,6 +932,8 @@ void orc_scene_destroy(orc_scene *s) {
 const ptx_scene_desc *orc_scene_desc(const orc_scene *s) { return &s->d; }
 
 void orc_first_hit(const orc_scene *s, const ptx_ray *rays, int n, ptx_hit *hits) {
+    /* rays are independent; threads only matter for scenes of a million objects */
+#pragma omp parallel for schedule(dynamic, 16) if (n >= 64 && s->d.n_objects > 100000)
     for (int i = 0; i < n; i++) {
         pt p0 = {rays[i].p0[0], rays[i].p0[1], rays[i].p0[2], 1};
         pt d = {rays[i].d[0], rays[i].d[1], rays[i].d[2], 1};

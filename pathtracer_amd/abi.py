@@ -73,6 +73,11 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_hits", C.c_uint64), ("shadow_rays", C.c_uint64), ("rindex_oob", C.c_uint64)]
 
 
+class WalkStats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("hits", C.c_uint64), ("list_tests", C.c_uint64), ("node_visits", C.c_uint64),
+                ("leaf_tests", C.c_uint64 * 6), ("texel_lookups", C.c_uint64)]
+
+
 class TonemapInfo(C.Structure):
     _fields_ = [("min", C.c_double), ("max", C.c_double), ("low_cut", C.c_double), ("high_cut", C.c_double),
                 ("recomputed_on_host", C.c_uint64)]

@@ -67,8 +67,11 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     double e = fma(-x * y, y, 1.0);
     return fma(y * e, fma(0.375, e, 0.5), y);
 }
-// 1/x as the box test wants it: +-infinity for a zero component, like the IEEE division
-__device__ __forceinline__ double rcp_or_inf(double x) { return x == 0.0 ? copysign(INFINITY, x) : fast_rcp(x); }
+// 1/x as the box test wants it.  For a direction component that is zero (or too small for its reciprocal to be
+// finite) the reference's (bound - p0) / d is -infinity or +infinity by the sign of bound - p0; a large finite
+// stand-in of the component's sign gives bound * r - p0 * r that sign too (an infinite one would give
+// inf - inf = NaN wherever bound and p0 have the same sign).  2^500 leaves room for coordinates up to 2^500.
+__device__ __forceinline__ double rcp_for_slab(double x) { return fabs(x) < 0x1p-500 ? copysign(0x1p500, x) : fast_rcp(x); }
 __device__ __forceinline__ V3 norm3(V3 v) {  // normalize(), reference utils_path.h:103-114
     return v * fast_rsqrt(dot3(v, v));
 }
@@ -398,8 +401,13 @@ __device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double
 //    interval is not empty, does not end behind the origin and does not start beyond the best hit so far; the
 //    reference's box_intersect (magic.c:457-474) is the same slab test without the last condition.  The node
 //    boxes are a little larger than the reference's, which keeps rounding from rejecting one it would enter.
-template <bool USE_BVH>
-__device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os) {
+// COUNT: the instrumented build -- wc receives how many list primitives, hierarchy nodes and leaf primitives (by
+// type) the query tested.
+struct WalkCount {
+    uint32_t queries, hits, list_tests, node_visits, leaf_tests[6], texel_lookups;
+};
+template <bool USE_BVH, bool COUNT = false>
+__device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os, WalkCount *wc = nullptr) {
     Hit h;
     h.lambda = INFINITY;
     h.obj = -1;
@@ -412,6 +420,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         int part;
         const int id = USE_BVH ? list_ids[k] : k;
         double lam = isect_any(list_geom + k, p0, d, dd, inv_dd, part);
+        if (COUNT) wc->list_tests++;
         if (id != os && lam > PT_TOL && lam < h.lambda) {
             h.lambda = lam;
             h.obj = id;
@@ -420,9 +429,10 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     }
     if (USE_BVH) {
         // slab test as b * (1/d) - p0 * (1/d): one fused multiply-add per plane.  It is less exact than
-        // (b - p0) / d near b = p0, by far less than the margin the node boxes carry (ptx_bvh.h); for a direction
-        // component of zero both planes give NaN, which fmin/fmax ignore: the slab then never rejects.
-        const double ix = rcp_or_inf(d.x), iy = rcp_or_inf(d.y), iz = rcp_or_inf(d.z);
+        // (b - p0) / d near b = p0, by far less than the margin the node boxes carry (ptx_bvh.h).  For a direction
+        // component of zero the two planes come out hugely negative and hugely positive if p0 lies between them
+        // (the slab then never rejects) and both on one side otherwise (the box is missed), as in the reference.
+        const double ix = rcp_for_slab(d.x), iy = rcp_for_slab(d.y), iz = rcp_for_slab(d.z);
         const double ox = p0.x * ix, oy = p0.y * iy, oz = p0.z * iz;
         int node = 0;
         const int n_nodes = sc.n_bvh_nodes;
@@ -431,6 +441,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         const PtxBvhNode *nodes = sc.bvh + (size_t)octant * (size_t)n_nodes;
         while (node < n_nodes) {
             const PtxBvhNode nd = nodes[node];
+            if (COUNT) wc->node_visits++;
             double t0 = fma((double)nd.box[0], ix, -ox), t1 = fma((double)nd.box[1], ix, -ox);
             double t2 = fma((double)nd.box[2], iy, -oy), t3 = fma((double)nd.box[3], iy, -oy);
             double t4 = fma((double)nd.box[4], iz, -oz), t5 = fma((double)nd.box[5], iz, -oz);
@@ -443,6 +454,7 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
                 next = node + 1;
                 if (leaf >= 0 && id != os) {
                     int part;
+                    if (COUNT) wc->leaf_tests[(leaf >> PTX_LEAF_TYPE_SHIFT) & 7]++;
                     double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, dd, inv_dd, part);
                     if (lam > PT_TOL && (lam < h.lambda || (lam == h.lambda && id < h.obj))) {
                         h.lambda = lam;
@@ -453,6 +465,10 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
             }
             node = next;
         }
+    }
+    if (COUNT) {
+        wc->queries++;
+        if (h.obj >= 0) wc->hits++;
     }
     return h;
 }
@@ -880,13 +896,13 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
 // that has used up its depth ends without another trip through the loop.
 // With DEFER_GLOSSY the three normal deviates of a glossy mirror bounce (:460-464) are not drawn here: the
 // lane reports its refl_sig in `glossy` (0 otherwise) and the caller adds them with glossy_service().
-template <int FLAGS, bool USE_BVH, bool DEFER_GLOSSY>
+template <int FLAGS, bool USE_BVH, bool DEFER_GLOSSY, bool COUNT = false>
 __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt,
-                              double &glossy) {
+                              double &glossy, WalkCount *wc = nullptr) {
     glossy = 0;
     ps.d = norm3(ps.d);
     cnt.closest++;
-    Hit h = closest_hit_all<USE_BVH>(sc, ps.p0, ps.d, ps.os);
+    Hit h = closest_hit_all<USE_BVH, COUNT>(sc, ps.p0, ps.d, ps.os, wc);
     if (h.obj < 0) return true;
     const DevMat &mt = sc.mat[h.obj];
     const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
@@ -897,6 +913,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     double R = mt.col[0], G = mt.col[1], B = mt.col[2];
     if (tex_img >= 0) tex_map<USE_BVH>(sc, tex_img, a, b, R, G, B);
     if (normal_img >= 0) n = normal_deform<USE_BVH>(sc, normal_img, a, b, n);
+    if (COUNT) wc->texel_lookups += (tex_img >= 0) + (normal_img >= 0) + (alpha_img >= 0 && !mt.is_light);
     if (mt.is_light) {
         if (!ps.cel) ps.I = mk(ps.I.x + ps.col.x * R, ps.I.y + ps.col.y * G, ps.I.z + ps.col.z * B);
         return true;
@@ -945,7 +962,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             double d2 = dot3(dl, dl);
             V3 ed = dl * fast_rsqrt(d2);
             cnt.shadow++;
-            Hit sh = closest_hit_all<USE_BVH>(sc, p, ed, h.obj);
+            Hit sh = closest_hit_all<USE_BVH, COUNT>(sc, p, ed, h.obj, wc);
             int lit = 0;
             if (sh.obj >= 0) {
                 const DevMat &lm = sc.mat[sh.obj];

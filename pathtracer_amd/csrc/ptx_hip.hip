@@ -1,16 +1,12 @@
 // ptx_hip.hip -- kernels and C ABI of libptx_hip.so (gfx950 / MI355X).
 //
-// Execution model.  One lane owns one pixel for the whole launch and walks
-// through that pixel's samples in order: when its path ends it folds the
-// colour into the pixel's accumulator (held in registers), advances to the
-// next sample and starts a new primary ray in the same loop iteration, so a
-// wave stays busy until its slowest pixel has finished all samples.  This
-// keeps the reference's per-pixel, order-dependent accumulation
-// (PathTracer.c:643-652) exact without any inter-lane traffic, needs no
-// queues in HBM, and touches memory only to read the scene (scalar loads of
-// a few KB that stay in the scalar cache) and to load/store 32 bytes of
-// accumulator per pixel per launch.  A wave covers an 8x8 pixel tile so that
-// its lanes follow similar paths.
+// Execution model.  A render_passes call runs two kernels per round.  k_trace_samples: a wave owns a run of
+// consecutive samples of an 8x8 pixel tile, one lane per pixel; when a lane's path ends it writes the path's colour
+// to the sample buffer and starts its pixel's next sample in the same loop iteration, so the wave stays busy until
+// its slowest pixel has finished the run.  k_fold_samples: one lane per pixel folds the pixel's samples into the
+// accumulator in sample order, which keeps the reference's order-dependent accumulation (PathTracer.c:643-652)
+// exact.  The scene of a small configuration is read with wave-uniform addresses (scalar loads of a few KB that
+// stay in the scalar cache); larger scenes add a per-lane walk of the bounding-volume hierarchy.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -171,21 +167,31 @@ __global__ void __launch_bounds__(256) k_fold_samples(const double *__restrict__
 template <int FLAGS, bool USE_BVH>
 __global__ void __launch_bounds__(PTX_BLOCK) k_trace_paths(DevScene sc, DevRender rp, const int32_t *__restrict__ pi,
                                                             const int32_t *__restrict__ pj, const int32_t *__restrict__ pk,
-                                                            long n, double *__restrict__ out) {
+                                                            long n, double *__restrict__ out, unsigned long long *__restrict__ walk) {
     PTX_LANE_STORE(ls);
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
     Counters cnt = {0, 0, 0};
+    WalkCount wc = {};
     Path ps;
-    primary_ray(sc, rp, ls, pi[q], pj[q], pk[q], ps);
-    if (rp.max_depth >= 1) {
-        double glossy;
-        while (!bounce<FLAGS, USE_BVH, false>(sc, rp, ls, ps, cnt, glossy)) {
+    if (q < n) {
+        primary_ray(sc, rp, ls, pi[q], pj[q], pk[q], ps);
+        if (rp.max_depth >= 1) {
+            double glossy;
+            while (!bounce<FLAGS, USE_BVH, false, true>(sc, rp, ls, ps, cnt, glossy, &wc)) {
+            }
         }
+        out[3 * q + 0] = ps.I.x;
+        out[3 * q + 1] = ps.I.y;
+        out[3 * q + 2] = ps.I.z;
     }
-    out[3 * q + 0] = ps.I.x;
-    out[3 * q + 1] = ps.I.y;
-    out[3 * q + 2] = ps.I.z;
+    // this kernel is the instrumented build: what its queries tested, summed over the wave
+    unsigned long long v[PTX_N_WALK] = {wc.queries, wc.hits, wc.list_tests, wc.node_visits, wc.leaf_tests[0], wc.leaf_tests[1],
+                                        wc.leaf_tests[2], wc.leaf_tests[3], wc.leaf_tests[4], wc.leaf_tests[5], wc.texel_lookups};
+#pragma unroll
+    for (int c = 0; c < PTX_N_WALK; c++) {
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off);
+        if ((threadIdx.x & 63) == 0 && v[c]) atomicAdd(&walk[c], v[c]);
+    }
 }
 
 template <bool USE_BVH>
@@ -315,6 +321,19 @@ static void free_render(ptx_context *c) {
 extern "C" const char *ptx_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ptx_version(void) { return "0.1"; }
 
+extern "C" void ptx_shutdown(ptx_context *c);
+
+static int init_context(ptx_context *c) {
+    HIPCHK(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMalloc(&c->d_stats, PTX_N_STATS * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_stats, 0, PTX_N_STATS * sizeof(unsigned long long)));
+    return PTX_OK;
+}
+
 extern "C" int ptx_init(int device, ptx_context **out) {
     if (!out) return fail(PTX_EINVAL, "ptx_init: null output pointer");
     int ndev = 0;
@@ -323,13 +342,11 @@ extern "C" int ptx_init(int device, ptx_context **out) {
     HIPCHK(hipSetDevice(device));
     ptx_context *c = new ptx_context();
     c->device = device;
-    HIPCHK(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIPCHK(hipEventCreate(&c->ev0));
-    HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+    const int rc = init_context(c);
+    if (rc) {
+        ptx_shutdown(c);  // releases whatever had been created
+        return rc;
+    }
     *out = c;
     return PTX_OK;
 }
@@ -337,15 +354,15 @@ extern "C" int ptx_init(int device, ptx_context **out) {
 extern "C" void ptx_shutdown(ptx_context *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_render(c);
     free_scene(c);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_samples);
     for (hipEvent_t e : c->trace_ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
-    (void)hipStreamDestroy(c->own_stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -389,6 +406,12 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     free_scene(c);
+    // a failure part of the way leaves no half-built scene behind
+    struct Guard {
+        ptx_context *c;
+        bool done;
+        ~Guard() { if (!done) free_scene(c); }
+    } guard{c, false};
     const int n = s->n_objects;
     std::vector<DevGeom> geom(n);
     std::vector<DevMat> mat(n);
@@ -396,8 +419,13 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     for (int k = 0; k < n; k++) {
         const ptx_object &o = s->objects[k];
         if (o.type < PTX_PLANE || o.type > PTX_ROOM) return fail(PTX_EINVAL, "ptx_scene_upload: unknown object type");
+        // texMap and normalDeform read three channels per texel, alphaMap one (reference utils_path.c:1322-1406)
         for (int32_t img : {o.tex_img, o.normal_img, o.alpha_img})
-            if (img >= s->n_images) return fail(PTX_EINVAL, "ptx_scene_upload: image index out of range");
+            if (img < -1 || img >= s->n_images) return fail(PTX_EINVAL, "ptx_scene_upload: image index out of range");
+        if ((o.tex_img >= 0 && s->images[o.tex_img].channels != 3) || (o.normal_img >= 0 && s->images[o.normal_img].channels != 3))
+            return fail(PTX_EINVAL, "ptx_scene_upload: a texture or normal map must have three channels");
+        if (o.alpha_img >= 0 && s->images[o.alpha_img].channels != 1)
+            return fail(PTX_EINVAL, "ptx_scene_upload: an alpha map must have one channel");
         DevGeom &g = geom[k];
         memset(&g, 0, sizeof(g));
         g.type = o.type;
@@ -560,6 +588,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
                       (cam.C2W[4 * r + 3] * 1.0);
     c->n_objects = n;
     c->have_scene = true;
+    guard.done = true;
     return PTX_OK;
 }
 
@@ -598,7 +627,7 @@ extern "C" int ptx_render_begin(ptx_context *c, const ptx_render_params *p) {
     HIPCHK(hipMemsetAsync(c->d_rgb, 0, npix * 3 * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, c->d_wght, npix, 1.0);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_stats, 0, PTX_STATS_WALK * sizeof(unsigned long long), c->stream));
     c->rendering = true;
     c->have_timing = false;
     return PTX_OK;
@@ -614,7 +643,7 @@ extern "C" int ptx_render_begin_external(ptx_context *c, const ptx_render_params
     c->d_rgb = d_rgb;
     c->d_wght = d_wght;
     c->own_accum = false;
-    HIPCHK(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_stats, 0, PTX_STATS_WALK * sizeof(unsigned long long), c->stream));
     c->rendering = true;
     c->have_timing = false;
     return PTX_OK;
@@ -656,28 +685,17 @@ static size_t sample_buffer_cap(size_t already_ours) {
     return cap;
 }
 
-extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
-    if (!c) return fail(PTX_EINVAL, "null context");
-    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
-    if (k0 < 0 || nk < 0) return fail(PTX_EINVAL, "negative pass range");
-    if (nk == 0 || c->rp.rows_owned == 0) return PTX_OK;
-    HIPCHK(hipSetDevice(c->device));
+// Passes k0 .. k0+nk-1 in rounds of trace + fold through the sample buffer `buf` of `buf_bytes` bytes.
+// per_launch_timing: bracket every launch of the tracing kernel with events (created on demand).
+static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf_bytes, bool per_launch_timing) {
     const int tiles_x = (c->rp.sx + 7) / 8, tiles_y = (c->rp.rows_owned + 7) / 8;
     const long n_tiles = (long)tiles_x * tiles_y;
     const size_t n_pix = (size_t)c->rp.rows_owned * c->rp.sx;
-    const size_t bytes_per_pass = n_pix * PTX_SAMPLE_DOUBLES * sizeof(double);  // of four passes at a time: see stride
-    // samples per round: what the buffer may hold
-    const size_t cap = sample_buffer_cap(c->samples_bytes);
-    // a pixel's records start on a 128-byte line: the stride is a multiple of four records
-    const int round_max = (int)std::max<size_t>(4, std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (cap / bytes_per_pass) & ~(size_t)3));
-    if ((size_t)round_max * bytes_per_pass > c->samples_bytes) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->d_samples);
-        c->d_samples = nullptr;
-        c->samples_bytes = 0;
-        HIPCHK(hipMalloc((void **)&c->d_samples, (size_t)round_max * bytes_per_pass));
-        c->samples_bytes = (size_t)round_max * bytes_per_pass;
-    }
+    const size_t bytes_per_pass = n_pix * PTX_SAMPLE_DOUBLES * sizeof(double);
+    // samples per round: what the buffer holds; a pixel's records start on a 128-byte line, so the stride is a
+    // multiple of four records
+    const int round_max = (int)std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (buf_bytes / bytes_per_pass) & ~(size_t)3);
+    if (round_max < 4) return fail(PTX_EINVAL, "sample buffer too small for four passes of this image");
     const bool pinhole = c->rp.aperture == 0;
     const long slots = (long)c->n_cus * 4 * ((c->use_bvh || !pinhole) ? 3 : 4);  // waves the GPU holds at once
     // waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and
@@ -693,33 +711,58 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
         const int sub_len = (int)(((nka + n_sub - 1) / n_sub + 3) & ~3L);
         n_sub = (nka + sub_len - 1) / sub_len;
         if (n_tiles * n_sub > 0x7fffffffL) return fail(PTX_EINVAL, "ptx_render_passes: image too large for one launch");
-        while ((int)c->trace_ev.size() < 2 * (c->n_trace_launches + 1)) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));
-            c->trace_ev.push_back(e);
+        if (per_launch_timing) {
+            while ((int)c->trace_ev.size() < 2 * (c->n_trace_launches + 1)) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->trace_ev.push_back(e);
+            }
+            HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches], c->stream));
         }
-        HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches], c->stream));
         dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
             constexpr int F = decltype(fl)::value;
             constexpr bool B = decltype(bv)::value;
             const dim3 grid((unsigned)(n_tiles * n_sub));
             if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, (int)n_tiles, (size_t)round_max, c->d_samples, c->d_stats);
+                                   sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
             else
                 hipLaunchKernelGGL((k_trace_samples<F, B, false>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, (int)n_tiles, (size_t)round_max, c->d_samples, c->d_stats);
+                                   sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
         });
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches + 1], c->stream));
-        c->n_trace_launches++;
-        hipLaunchKernelGGL(k_fold_samples, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, c->stream, c->d_samples, n_pix, (size_t)round_max, nka,
+        if (per_launch_timing) {
+            HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches + 1], c->stream));
+            c->n_trace_launches++;
+        }
+        hipLaunchKernelGGL(k_fold_samples, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, c->stream, buf, n_pix, (size_t)round_max, nka,
                            c->d_rgb, c->d_wght);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     c->have_timing = true;
     return PTX_OK;
+}
+
+extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    if (k0 < 0 || nk < 0) return fail(PTX_EINVAL, "negative pass range");
+    if (nk == 0 || c->rp.rows_owned == 0) return PTX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n_pix = (size_t)c->rp.rows_owned * c->rp.sx;
+    const size_t bytes_per_pass = n_pix * PTX_SAMPLE_DOUBLES * sizeof(double);
+    const size_t cap = sample_buffer_cap(c->samples_bytes);
+    const size_t round_max = std::max<size_t>(4, std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (cap / bytes_per_pass) & ~(size_t)3));
+    if (round_max * bytes_per_pass > c->samples_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_samples);
+        c->d_samples = nullptr;
+        c->samples_bytes = 0;
+        HIPCHK(hipMalloc((void **)&c->d_samples, round_max * bytes_per_pass));
+        c->samples_bytes = round_max * bytes_per_pass;
+    }
+    return render_rounds(c, k0, nk, c->d_samples, round_max * bytes_per_pass, true);  // the cap, not what an earlier call left
 }
 
 extern "C" int ptx_sync(ptx_context *c) {
@@ -856,6 +899,18 @@ extern "C" int ptx_get_stats(ptx_context *c, ptx_stats *st) {
     return PTX_OK;
 }
 
+extern "C" int ptx_last_walk_stats(ptx_context *c, ptx_walk_stats *ws) {
+    if (!c || !ws) return fail(PTX_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long h[PTX_N_WALK];
+    HIPCHK(hipMemcpy(h, c->d_stats + PTX_STATS_WALK, sizeof(h), hipMemcpyDeviceToHost));
+    ws->queries = h[0]; ws->hits = h[1]; ws->list_tests = h[2]; ws->node_visits = h[3];
+    for (int q = 0; q < 6; q++) ws->leaf_tests[q] = h[4 + q];
+    ws->texel_lookups = h[10];
+    return PTX_OK;
+}
+
 extern "C" int ptx_first_hit_device(ptx_context *c, const ptx_ray *d_rays, int64_t n, ptx_hit *d_hits) {
     if (!c || (n > 0 && (!d_rays || !d_hits))) return fail(PTX_EINVAL, "null argument");
     if (!c->have_scene) return fail(PTX_ESTATE, "no scene uploaded");
@@ -923,17 +978,22 @@ extern "C" int ptx_trace_paths(ptx_context *c, const ptx_render_params *p, const
         (void)hipFree(d_idx);
         return fail(PTX_ENOMEM, "ptx_trace_paths: out of device memory");
     }
-    (void)hipMemcpyAsync(d_idx, pi, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    (void)hipMemcpyAsync(d_idx + n, pj, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    (void)hipMemcpyAsync(d_idx + 2 * n, pk, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    dispatch_flags(p->flags, c->use_bvh, [&](auto fl, auto bv) {
-        constexpr int F = decltype(fl)::value;
-        constexpr bool B = decltype(bv)::value;
-        hipLaunchKernelGGL((k_trace_paths<F, B>), dim3((unsigned)((n + PTX_BLOCK - 1) / PTX_BLOCK)), dim3(PTX_BLOCK), 0, c->stream, c->sc, rp, d_idx,
-                           d_idx + n, d_idx + 2 * n, (long)n, d_out);
-    });
     rc = PTX_OK;
-    if (hipGetLastError() != hipSuccess) rc = fail(PTX_EDEVICE, "ptx_trace_paths: launch failed");
+    if (hipMemsetAsync(c->d_stats + PTX_STATS_WALK, 0, PTX_N_WALK * sizeof(unsigned long long), c->stream) != hipSuccess)
+        rc = fail(PTX_EDEVICE, "ptx_trace_paths: clearing the counters failed");
+    if (!rc && (hipMemcpyAsync(d_idx, pi, (size_t)n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_idx + n, pj, (size_t)n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_idx + 2 * n, pk, (size_t)n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess))
+        rc = fail(PTX_EDEVICE, "ptx_trace_paths: copy to device failed");
+    if (!rc) {
+        dispatch_flags(p->flags, c->use_bvh, [&](auto fl, auto bv) {
+            constexpr int F = decltype(fl)::value;
+            constexpr bool B = decltype(bv)::value;
+            hipLaunchKernelGGL((k_trace_paths<F, B>), dim3((unsigned)((n + PTX_BLOCK - 1) / PTX_BLOCK)), dim3(PTX_BLOCK), 0, c->stream, c->sc, rp, d_idx,
+                               d_idx + n, d_idx + 2 * n, (long)n, d_out, c->d_stats + PTX_STATS_WALK);
+        });
+        if (hipGetLastError() != hipSuccess) rc = fail(PTX_EDEVICE, "ptx_trace_paths: launch failed");
+    }
     if (!rc && hipMemcpyAsync(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         rc = fail(PTX_EDEVICE, "ptx_trace_paths: copy from device failed");
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(PTX_EDEVICE, "ptx_trace_paths: kernel failed");

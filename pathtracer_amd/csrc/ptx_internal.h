@@ -10,6 +10,11 @@
 
 #include "ptx_hip.h"
 
+// Device counters of a context: [0..3] paths, closest-hit queries, shadow queries, out-of-range refraction-stack
+// accesses of the render kernels since ptx_render_begin; [PTX_STATS_WALK ..] the ptx_walk_stats fields of the last
+// ptx_trace_paths call.
+enum { PTX_STATS_WALK = 4, PTX_N_WALK = 11, PTX_N_STATS = PTX_STATS_WALK + PTX_N_WALK };
+
 // Tone-maps n accumulator values on the device (d_im) into n bytes on the host; returns a PTX_* code and, on
 // failure, a message in err.  Defined in ptx_tonemap.hip.
 int ptx_tonemap_run(hipStream_t stream, const double *d_im, size_t n, uint8_t *h_bits, ptx_tonemap_info *info, std::string &err);

@@ -18,7 +18,7 @@ EXPORTS = [
     "ptx_init", "ptx_shutdown", "ptx_scene_upload", "ptx_render_begin", "ptx_render_begin_external",
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_last_trace_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
-    "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload",
+    "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload", "ptx_last_walk_stats",
 ]
 
 
@@ -53,6 +53,7 @@ def load_library(path=None):
     lib.ptx_first_hit_device.argtypes = [vp, vp, C.c_int64, vp]
     lib.ptx_trace_paths.argtypes = [vp, C.POINTER(abi.RenderParams), vp, vp, vp, C.c_int64, vp]
     lib.ptx_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    lib.ptx_last_walk_stats.argtypes = [vp, C.POINTER(abi.WalkStats)]
     lib.ptx_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ptx_last_trace_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ptx_set_stream.argtypes = [vp, vp]
@@ -173,6 +174,13 @@ class Device:
         s = abi.Stats()
         self._check(self.lib.ptx_get_stats(self.ctx, C.byref(s)))
         return {"paths": s.paths, "closest_hits": s.closest_hits, "shadow_rays": s.shadow_rays, "rindex_oob": s.rindex_oob}
+
+    def last_walk_stats(self):
+        """What the queries of the last trace_paths call tested (the instrumented path kernel)."""
+        w = abi.WalkStats()
+        self._check(self.lib.ptx_last_walk_stats(self.ctx, C.byref(w)))
+        return {"queries": w.queries, "hits": w.hits, "list_tests": w.list_tests, "node_visits": w.node_visits,
+                "leaf_tests": list(w.leaf_tests), "texel_lookups": w.texel_lookups}
 
     def last_pass_ms(self):
         ms = C.c_float()

@@ -29,48 +29,86 @@ def local_row_count(sx, rank, world, band_rows):
     return abi.rows_owned(sx, rank, world, band_rows)
 
 
-_ROW_INDEX_CACHE = {}
+def hip_runtime_copies():
+    """Paths of the HIP runtime libraries mapped into this process.  A hipStream_t is only meaningful inside the
+    copy of the runtime that created it: handing PyTorch's stream to libptx_hip.so (Device.set_stream) is valid
+    when both resolved to one libamdhip64 (they do when the sonames agree: the dynamic linker loads one)."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
 
 
-def _global_rows_tensor(sx, r, world, band_rows, device):
-    """Whole-image row numbers of rank r's rows as an index tensor on `device` (built once per split)."""
-    key = (sx, r, world, band_rows, str(device))
-    t = _ROW_INDEX_CACHE.get(key)
-    if t is None:
-        t = torch.as_tensor(abi.global_rows(sx, r, world, band_rows), device=device)
-        _ROW_INDEX_CACHE[key] = t
-    return t
+class Gatherer:
+    """Accumulators of one rank and their gather to `dst`, with every buffer allocated once.
+
+    `local` is one tensor: this rank's rgb rows (rows*sx*3 doubles) at the front, its weights (rows*sx doubles) at
+    offset max_rows*sx*3, max_rows being the largest share of any rank, so that the whole tensor is the message
+    and nothing is packed before a gather.  On `dst`, `rgb` and `wght` are the whole image (row order of the
+    reference's rgbIm and wght, PathTracer.c:550-557)."""
+
+    def __init__(self, sx, rank, world, band_rows, device, dst=0, group=None):
+        self.sx, self.rank, self.world, self.band_rows, self.dst, self.group = sx, rank, world, band_rows, dst, group
+        self.counts = [abi.rows_owned(sx, r, world, band_rows) for r in range(world)]
+        self.rows = self.counts[rank]
+        self.max_rows = max(self.counts)
+        self.local = torch.zeros(self.max_rows * sx * 4, dtype=torch.float64, device=device)
+        self.rgb_local = self.local[: self.rows * sx * 3]
+        self.wght_local = self.local[self.max_rows * sx * 3: self.max_rows * sx * 3 + self.rows * sx]
+        self.is_dst = rank == dst
+        self.via_host = world > 1 and self.local.is_cuda and dist.get_backend(group) == "gloo"
+        self.rgb = self.wght = None
+        self.bufs = None
+        if world == 1:
+            self.rgb, self.wght = self.rgb_local.view(sx, sx, 3), self.wght_local.view(sx, sx)
+        elif self.is_dst:
+            self.rgb = torch.empty(sx, sx, 3, dtype=torch.float64, device=device)
+            self.wght = torch.empty(sx, sx, dtype=torch.float64, device=device)
+            buf_dev = "cpu" if self.via_host else device
+            self.bufs = [torch.empty(self.max_rows * sx * 4, dtype=torch.float64, device=buf_dev) for _ in range(world)]
+            self.row_index = [torch.as_tensor(abi.global_rows(sx, r, world, band_rows), device=device) for r in range(world)]
+        if self.via_host:
+            self.staged = torch.empty(self.max_rows * sx * 4, dtype=torch.float64, device="cpu")
+
+    def reset(self):
+        """rgb = 0, weights = 1 (newImage and the wght loop, PathTracer.c:550-557)."""
+        self.rgb_local.zero_()
+        self.wght_local.fill_(1.0)
+
+    def gather(self):
+        """Collects every rank's rows on dst; returns (rgb, wght) whole-image tensors there, (None, None) elsewhere."""
+        sx = self.sx
+        if self.world == 1:
+            return self.rgb, self.wght
+        if self.via_host:  # gloo moves host tensors only (a rehearsal of the GPU path without RCCL)
+            self.staged.copy_(self.local)
+            dist.gather(self.staged, self.bufs, dst=self.dst, group=self.group)
+        else:
+            dist.gather(self.local, self.bufs, dst=self.dst, group=self.group)
+        if not self.is_dst:
+            return None, None
+        for r in range(self.world):
+            n = self.counts[r]
+            buf = self.bufs[r].to(self.rgb.device, non_blocking=True) if self.via_host else self.bufs[r]
+            self.rgb.index_copy_(0, self.row_index[r], buf[: n * sx * 3].view(n, sx, 3))
+            self.wght.index_copy_(0, self.row_index[r], buf[self.max_rows * sx * 3: self.max_rows * sx * 3 + n * sx].view(n, sx))
+        return self.rgb, self.wght
 
 
 def gather_accumulators(rgb_local, wght_local, sx, rank, world, band_rows, dst=0, group=None):
-    """Collects every rank's rows on `dst` and returns whole-image tensors there (None elsewhere).
+    """One-off form of Gatherer.gather for accumulators held elsewhere: copies them in, gathers, returns whole-image
+    tensors on `dst` (None elsewhere).
 
     rgb_local: (rows_owned*sx*3,) float64, wght_local: (rows_owned*sx,) float64, in local row order.
     """
     if world == 1:
         return rgb_local.view(sx, sx, 3), wght_local.view(sx, sx)
-    counts = [abi.rows_owned(sx, r, world, band_rows) for r in range(world)]
-    max_rows = max(counts)
-    # one message per rank: rgb and wght of a row side by side, padded to the largest share
-    packed = torch.zeros(max_rows, sx, 4, dtype=torch.float64, device=rgb_local.device)
-    n = counts[rank]
-    packed[:n, :, :3] = rgb_local.view(n, sx, 3)
-    packed[:n, :, 3] = wght_local.view(n, sx)
-    if packed.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo gathers host tensors only (a rehearsal of the GPU path without RCCL)
-        staged = packed.cpu()
-        host_bufs = [torch.empty_like(staged) for _ in range(world)] if rank == dst else None
-        dist.gather(staged, host_bufs, dst=dst, group=group)
-        bufs = [b.to(packed.device) for b in host_bufs] if rank == dst else None
-    else:
-        bufs = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
-        dist.gather(packed, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None, None
-    rgb = torch.empty(sx, sx, 3, dtype=torch.float64, device=rgb_local.device)
-    wght = torch.empty(sx, sx, dtype=torch.float64, device=rgb_local.device)
-    for r in range(world):
-        rows = _global_rows_tensor(sx, r, world, band_rows, rgb_local.device)
-        rgb[rows] = bufs[r][: counts[r], :, :3]
-        wght[rows] = bufs[r][: counts[r], :, 3]
-    return rgb, wght
+    g = Gatherer(sx, rank, world, band_rows, rgb_local.device, dst=dst, group=group)
+    g.rgb_local.copy_(rgb_local)
+    g.wght_local.copy_(wght_local)
+    return g.gather()

@@ -7,12 +7,124 @@ from pathtracer_amd import abi
 FIRST_HIT_RTOL = 1e-5
 
 
-def compare_hits(got, want, scene, rtol=FIRST_HIT_RTOL, exact=False, max_id_mismatch=0):
-    """Asserts that two ptx_hit arrays describe the same hits.  Texture coordinates are compared except for
-    triangles and rooms, where the reference leaves them unset."""
+TIE_RTOL = 1e-9
+
+
+def prove_ties(rays, got, want, requery):
+    """For rays on which two implementations name different objects: shows that the ray meets both objects at the
+    same distance to within rounding (the reference keeps whichever it visits first, PathTracer.c:233, and the two
+    sides need not round alike).  `requery(rays)` is the first-hit function that produced `got`.  Proof for one ray:
+    the two lambdas agree to TIE_RTOL, and with its own winner excluded (os = its winner) the implementation under
+    test finds the other side's object, again at that distance.  Returns the indices of the rays for which the proof
+    fails."""
+    bad = np.nonzero(got["obj"] != want["obj"])[0]
+    if len(bad) == 0:
+        return bad
+    unproven = []
+    again = np.array(rays[bad], copy=True)
+    again["os"] = got["obj"][bad]
+    second = requery(again)
+    for q, r in enumerate(bad):
+        lam = want["lambda"][r]
+        ok = got["obj"][r] >= 0 and want["obj"][r] >= 0 and abs(got["lambda"][r] - lam) <= TIE_RTOL * abs(lam)
+        ok = ok and second["obj"][q] == want["obj"][r] and abs(second["lambda"][q] - lam) <= TIE_RTOL * abs(lam)
+        # the re-query drops the ray's own exclusion; if that object then comes first the proof is not available
+        if not ok:
+            unproven.append(r)
+    return np.asarray(unproven, dtype=np.int64)
+
+
+def _ref_box_test(p0, d, box):
+    """box_intersect of the reference (magic.c:457-474) with its comparison macros (min(A,B) = A > B ? B : A,
+    max(A,B) = A < B ? B : A), which pass a NaN on or drop it depending on the side it comes from."""
+    def rmin(a, b):
+        return b if a > b else a
+
+    def rmax(a, b):
+        return b if a < b else a
+
+    with np.errstate(all="ignore"):
+        l = [(np.float64(box[2 * a + s]) - p0[a]) / d[a] for a in range(3) for s in range(2)]
+    lmin = rmax(rmax(rmin(l[0], l[1]), rmin(l[2], l[3])), rmin(l[4], l[5]))
+    lmax = rmin(rmin(rmax(l[0], l[1]), rmax(l[2], l[3])), rmax(l[4], l[5]))
+    return bool(lmin <= lmax and lmax >= 0)
+
+
+def _slab_test_in_exact_arithmetic(p0, d, box):
+    """The same test with a zero direction component treated as geometry demands: the ray stays between the two
+    planes of that axis or it does not."""
+    lo, hi = -np.inf, np.inf
+    for a in range(3):
+        if d[a] == 0:
+            if not (box[2 * a] <= p0[a] <= box[2 * a + 1]):
+                return False
+            continue
+        t = sorted(((box[2 * a] - p0[a]) / d[a], (box[2 * a + 1] - p0[a]) / d[a]))
+        lo, hi = max(lo, t[0]), min(hi, t[1])
+    return bool(lo <= hi and hi >= 0)
+
+
+def _boxes_on_the_way_to(scene, obj):
+    """Boxes the reference's findFirstHit tests before it reaches object `obj`: those of the BoxTree nodes from the
+    root down to the node that holds the object, then the object's own (PathTracer.c:212-222)."""
+    nodes = scene.nodes
+    chain = []
+
+    def walk(n):
+        if n < 0:
+            return False
+        nd = nodes[n]
+        if nd["first_obj"] <= obj < nd["first_obj"] + nd["n_objs"] or walk(nd["child1"]) or walk(nd["child2"]):
+            chain.append(nd["box"])
+            return True
+        return False
+
+    import sys
+
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    if len(nodes):
+        walk(0)
+    return chain[::-1] + [scene.objects["box"][obj]]
+
+
+def explain_degenerate(ray, got, want, scene):
+    """Why an implementation that finds the geometrically closest hit may differ from the reference on a ray that
+    is not a tie.  Returns a reason or None.
+      "slab": a direction component is exactly zero and the origin lies exactly on a bounding plane of the nearer
+              object's box (or of a BoxTree node above it): the reference's slab test computes 0/0 there, its
+              comparison macros turn the NaN into a rejection, and it never tests the object.
+      "surface": the ray starts on the surface of the object one side reports (lambda below 1e-6): whether a
+              surface is hit again from a point on it is decided by rounding (the reference's only guard is
+              lambda > 1e-9, PathTracer.c:233)."""
+    p0, d = ray["p0"], ray["d"]
+    lams = [h["lambda"] for h in (got, want) if h["obj"] >= 0]
+    if lams and min(lams) < 1e-6:
+        return "surface"
+    if np.any(d == 0) and got["obj"] >= 0 and (want["obj"] < 0 or got["lambda"] < want["lambda"]):
+        for box in _boxes_on_the_way_to(scene, int(got["obj"])):
+            if not _ref_box_test(p0, d, box) and _slab_test_in_exact_arithmetic(p0, d, box):
+                return "slab"
+    return None
+
+
+def compare_hits(got, want, scene, rtol=FIRST_HIT_RTOL, exact=False, rays=None, requery=None, label="", degenerate_ok=False):
+    """Asserts that two ptx_hit arrays describe the same hits: object ids equal -- except on rays proven to meet
+    two objects at the same distance (prove_ties; needs `rays` and `requery`) -- and the rest within rtol.  Texture
+    coordinates are compared except for triangles and rooms, where the reference leaves them unset."""
     assert len(got) == len(want)
     id_bad = got["obj"] != want["obj"]
-    assert int(id_bad.sum()) <= max_id_mismatch, f"{int(id_bad.sum())} object ids differ (first at {np.argmax(id_bad)})"
+    if id_bad.any():
+        assert requery is not None, f"{int(id_bad.sum())} object ids differ (first at {np.argmax(id_bad)})"
+        unproven = prove_ties(rays, got, want, requery)
+        msg = f"{label}: {int(id_bad.sum())} of {len(got)} rays name another object than the reference, " \
+              f"{int(id_bad.sum()) - len(unproven)} of them proven ties"
+        if degenerate_ok and len(unproven):
+            # rays built to be degenerate (origins on bounding planes, exactly axis-parallel): see explain_degenerate
+            reasons = [explain_degenerate(rays[r], got[r], want[r], scene) for r in unproven]
+            msg += "".join(f", {reasons.count(k)} {k}" for k in ("slab", "surface") if k in reasons)
+            unproven = np.asarray([r for r, why in zip(unproven, reasons) if why is None], dtype=np.int64)
+        print(msg)
+        assert len(unproven) == 0, f"object ids differ without a tie on rays {unproven[:8]}"
     m = (want["obj"] >= 0) & ~id_bad
     types = scene.objects["type"][want["obj"][m]]
     uv_defined = (types != abi.TRIANGLE) & (types != abi.ROOM)

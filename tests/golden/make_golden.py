@@ -102,9 +102,34 @@ def scene_to_npz(scene, path):
                         texels=scene.texels, camera=scene.camera)
 
 
+def mixed_flag_vectors(tmp):
+    """Path radiances from the six builds of the reference with some but not all of IS / ES / RR
+    (reference Makefile:6-16), on the Cornell box and on the scene with every primitive type."""
+    rng = np.random.default_rng(606)
+    out = {}
+    objs, cam = prims_scene()
+    for name, sx, depth, ap in (("cornell", 48, 6, 0.0), ("prims", 40, 8, 0.1)):
+        n = 1200
+        pi, pj, pk = rng.integers(0, sx, n), rng.integers(0, sx, n), rng.integers(0, 32, n)
+        out.update({f"{name}_sx": sx, f"{name}_depth": depth, f"{name}_aperture": ap, f"{name}_seed": 515,
+                    f"{name}_pi": pi, f"{name}_pj": pj, f"{name}_pk": pk})
+        for f in range(1, 7):
+            r = Ref(f)
+            if name == "cornell":
+                r.select_scene("cornell", depth)
+            else:
+                r.build_custom(objs, cam, depth, asset_dir=tmp)
+            out[f"{name}_col_f{f}"] = r.trace_pixels(sx, pi, pj, pk, ap, 515)
+    np.savez_compressed(os.path.join(HERE, "mixed_flags_paths.npz"), **out)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="ptx_golden_")
     synthetic_assets(tmp)
+    if "--mixed-only" in sys.argv:
+        mixed_flag_vectors(tmp)
+        shutil.rmtree(tmp)
+        return
     rng = np.random.default_rng(2025)
     refs = {f: Ref(f) for f in (0, 7)}
     ref = refs[7]
@@ -242,6 +267,7 @@ def main():
         col = ref.trace_pixels(sx, pi, pj, pk, ap, 9)
         np.savez_compressed(os.path.join(HERE, f"{name}_paths_f7.npz"), sx=sx, depth=depth, seed=9, aperture=ap, pi=pi, pj=pj,
                             pk=pk, col=col)
+    mixed_flag_vectors(tmp)
     shutil.rmtree(tmp)
     for fn in sorted(os.listdir(HERE)):
         print(f"{os.path.getsize(os.path.join(HERE, fn)):9d}  {fn}")

@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -59,6 +60,40 @@ def test_two_ranks_equal_one(tmp_path):
     scene = pt.Scene.load(os.path.join(REPO, "tests", "golden", "cornell.ptxscene"))
     rgb, w, _ = Oracle(scene).render(pt.make_params(SX, 6, 7, 0.0, seed=9), 0, SPP)
     assert np.array_equal(z["rgb"].reshape(-1), rgb) and np.array_equal(z["w"].reshape(-1), w)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_started_without_a_launcher(world, tmp_path):
+    """pathtracer_amd.launch.launch_ranks, which `python bench.py --gpus N` uses when it was not started by
+    torch.distributed.run: the parent starts the ranks, hands on rank 0's line, and the gathered image equals the
+    single-process render bit for bit (uneven shares at three ranks: 24 rows in bands of 8)."""
+    import json
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import pathtracer_amd as pt
+    from harness import Oracle
+    from pathtracer_amd import launch
+
+    out = str(tmp_path / "gathered.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    rc, text = launch.launch_ranks([sys.executable, os.path.join(REPO, "tests", "multirank_child.py"), out], world, env=env, timeout=300)
+    assert rc == 0, text
+    line = json.loads(text.strip().splitlines()[-1])
+    assert line["world"] == world and sum(line["rows"]) == SX
+    z = np.load(out)
+    scene = pt.Scene.load(os.path.join(REPO, "tests", "golden", "cornell.ptxscene"))
+    rgb, w, _ = Oracle(scene).render(pt.make_params(SX, 6, 7, 0.0, seed=9), 0, SPP)
+    assert np.array_equal(z["rgb"].reshape(-1), rgb) and np.array_equal(z["w"].reshape(-1), w)
+
+
+def test_a_failing_rank_fails_the_launch(tmp_path):
+    from pathtracer_amd import launch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GLOO_SOCKET_IFNAME"] = env.get("GLOO_SOCKET_IFNAME", "lo")
+    rc, _ = launch.launch_ranks([sys.executable, os.path.join(REPO, "tests", "multirank_child.py"), str(tmp_path / "x.npz"), "0"], 1,
+                                env=env, timeout=120)
+    assert rc == 3
 
 
 def test_band_height_shrinks_for_small_images():

@@ -49,6 +49,16 @@ def test_path_radiance_matches_reference(name, flags, oracles, golden_dir):
         assert np.abs(got - z["col_dof"]).max() <= PATH_ATOL
 
 
+@pytest.mark.parametrize("flags", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("name", ["cornell", "prims"])
+def test_path_radiance_matches_reference_mixed_switches(name, flags, oracles, golden_dir):
+    """The six builds of the reference with some but not all of IS, ES and RR."""
+    z = np.load(os.path.join(golden_dir, "mixed_flags_paths.npz"))
+    prm = pt.make_params(int(z[f"{name}_sx"]), int(z[f"{name}_depth"]), flags, float(z[f"{name}_aperture"]), seed=int(z[f"{name}_seed"]))
+    got = oracles[name].trace_pixels(prm, z[f"{name}_pi"], z[f"{name}_pj"], z[f"{name}_pk"])
+    assert np.abs(got - z[f"{name}_col_f{flags}"]).max() <= PATH_ATOL
+
+
 @pytest.mark.parametrize("name,flags", [("cornell", 0), ("cornell", 7), ("prims", 0), ("prims", 7)])
 def test_render_matches_reference(name, flags, oracles, golden_dir):
     z = np.load(os.path.join(golden_dir, f"{name}_paths_f{flags}.npz"))

@@ -13,7 +13,7 @@ import pathtracer_amd as pt
 from checks import compare_hits
 from harness import Oracle, Ref, random_rays, ref_available
 
-pytestmark = pytest.mark.skipif(not ref_available(7) or not ref_available(0), reason="compiled reference not available")
+pytestmark = pytest.mark.skipif(not all(ref_available(f) for f in range(8)), reason="compiled reference not available")
 
 CASES = [("cornell", 6, 0.0), ("scifi", 12, 0.05), ("bubbletea", 12, 0.15)]
 
@@ -25,7 +25,7 @@ def tmpdir():
 
 
 @pytest.mark.parametrize("name,depth,aperture", CASES)
-@pytest.mark.parametrize("flags", [0, 7])
+@pytest.mark.parametrize("flags", list(range(8)))  # every build of the reference Makefile: IS | ES << 1 | RR << 2
 def test_first_hit_and_render_bit_exact(name, depth, aperture, flags, tmpdir):
     ref = Ref(flags)
     ref.select_scene(name, depth)  # shipped scene with whatever assets the checkout holds
