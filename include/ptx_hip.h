@@ -21,6 +21,8 @@
 #ifndef PTX_HIP_H
 #define PTX_HIP_H
 
+#include <stddef.h>
+
 #include "ptx_scene.h"
 
 #ifdef __cplusplus
@@ -83,6 +85,19 @@ int ptx_render_begin_external(ptx_context *ctx, const ptx_render_params *params,
  * into the accumulators in pass order afterwards; a call too large for the
  * buffer is carried out in several rounds, with the same result. */
 int ptx_render_passes(ptx_context *ctx, int k0, int nk);
+
+/* ptx_render_passes for callers that cannot allocate device memory (code under HIP graph capture, serving loops
+ * and harnesses that forbid hipMalloc).  No counterpart in the reference.  It allocates nothing: the traced
+ * samples go through a fixed 256 MiB array in the library's device image (one per GPU, held until the process
+ * ends) instead of the buffer ptx_render_passes allocates, in as many rounds of trace + fold as that takes (eight
+ * passes a round at 1024 x 1024); the accumulators are the ones ptx_render_begin or ptx_render_begin_external
+ * set up, and the result is the same bit for bit.  Limits: this rank's share of the image may have at most
+ * ptx_static_max_pixels() = 2 097 152 pixels (PTX_EINVAL beyond, e.g. a whole 2048 x 2048 image on one rank);
+ * ptx_last_trace_ms reports no launches for it (per-launch events would have to be created).  All contexts on
+ * one GPU share the array: calls that overlap in time on one GPU race; calls in sequence need no clearing (every
+ * record is written before it is read). */
+int ptx_render_passes_static(ptx_context *ctx, int k0, int nk);
+size_t ptx_static_max_pixels(void);
 
 /* Waits for queued work (the reference's loop is synchronous). */
 int ptx_sync(ptx_context *ctx);

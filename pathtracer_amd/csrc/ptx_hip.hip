@@ -264,6 +264,13 @@ __global__ void k_selftest(double *out) {
     }
 }
 
+// Sample buffer of ptx_render_passes_static, the entry point for callers that cannot allocate device memory: a
+// fixed array in the library's own device image, one copy per GPU, held until the process ends.  Host code never
+// uses this name as an address: ptx_init asks the runtime for the device address (hipGetSymbolAddress) once per
+// context, with the context's device current, and everything else goes through that pointer.
+#define PTX_STATIC_SAMPLE_BYTES ((size_t)256 << 20)
+static __device__ __align__(256) unsigned char scratch[PTX_STATIC_SAMPLE_BYTES];
+
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -288,6 +295,7 @@ struct ptx_context {
     int n_cus = 256;                 // compute units of the device
     double *d_samples = nullptr;     // sample buffer of the render kernels, grown on demand
     size_t samples_bytes = 0;
+    double *d_static_samples = nullptr;  // this device's copy of `scratch`
     // scene
     bool have_scene = false;
     DevScene sc{};
@@ -331,6 +339,7 @@ static int init_context(ptx_context *c) {
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc(&c->d_stats, PTX_N_STATS * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->d_stats, 0, PTX_N_STATS * sizeof(unsigned long long)));
+    HIPCHK(hipGetSymbolAddress((void **)&c->d_static_samples, HIP_SYMBOL(scratch)));  // the current device's copy
     return PTX_OK;
 }
 
@@ -764,6 +773,21 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     }
     return render_rounds(c, k0, nk, c->d_samples, round_max * bytes_per_pass, true);  // the cap, not what an earlier call left
 }
+
+extern "C" int ptx_render_passes_static(ptx_context *c, int k0, int nk) {
+    if (!c) return fail(PTX_EINVAL, "null context");
+    if (!c->rendering) return fail(PTX_ESTATE, "ptx_render_begin has not been called");
+    if (k0 < 0 || nk < 0) return fail(PTX_EINVAL, "negative pass range");
+    if (nk == 0 || c->rp.rows_owned == 0) return PTX_OK;
+    const size_t n_pix = (size_t)c->rp.rows_owned * c->rp.sx;
+    if (n_pix > PTX_STATIC_SAMPLE_BYTES / (4 * PTX_SAMPLE_DOUBLES * sizeof(double)))
+        return fail(PTX_EINVAL, "ptx_render_passes_static: more than 2097152 pixels on this rank (the fixed 256 MiB sample buffer "
+                                "holds four passes of at most that many); use ptx_render_passes or more ranks");
+    HIPCHK(hipSetDevice(c->device));
+    return render_rounds(c, k0, nk, c->d_static_samples, PTX_STATIC_SAMPLE_BYTES, false);
+}
+
+extern "C" size_t ptx_static_max_pixels(void) { return PTX_STATIC_SAMPLE_BYTES / (4 * PTX_SAMPLE_DOUBLES * sizeof(double)); }
 
 extern "C" int ptx_sync(ptx_context *c) {
     if (!c) return fail(PTX_EINVAL, "null context");

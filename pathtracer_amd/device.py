@@ -19,6 +19,7 @@ EXPORTS = [
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_last_trace_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
     "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload", "ptx_last_walk_stats",
+    "ptx_render_passes_static", "ptx_static_max_pixels",
 ]
 
 
@@ -45,6 +46,8 @@ def load_library(path=None):
     lib.ptx_render_begin.argtypes = [vp, C.POINTER(abi.RenderParams)]
     lib.ptx_render_begin_external.argtypes = [vp, C.POINTER(abi.RenderParams), vp, vp]
     lib.ptx_render_passes.argtypes = [vp, C.c_int, C.c_int]
+    lib.ptx_render_passes_static.argtypes = [vp, C.c_int, C.c_int]
+    lib.ptx_static_max_pixels.restype = C.c_size_t
     lib.ptx_sync.argtypes = [vp]
     lib.ptx_download.argtypes = [vp, vp, vp]
     lib.ptx_upload.argtypes = [vp, vp, vp]
@@ -108,6 +111,10 @@ class Device:
 
     def render_passes(self, k0, nk):
         self._check(self.lib.ptx_render_passes(self.ctx, k0, nk))
+
+    def render_passes_static(self, k0, nk):
+        """render_passes without any allocation: the samples go through the library's fixed device array."""
+        self._check(self.lib.ptx_render_passes_static(self.ctx, k0, nk))
 
     def sync(self):
         self._check(self.lib.ptx_sync(self.ctx))
