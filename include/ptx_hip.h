@@ -143,6 +143,17 @@ int ptx_upload(ptx_context *ctx, const double *rgbIm, const double *wght);
  * hold (for a device-side gather).  */
 int ptx_accumulators(ptx_context *ctx, double **d_rgb, double **d_wght, int32_t *rows_owned);
 
+/* Number of HIP devices.  The reference has none. */
+int ptx_device_count(int *n);
+
+/* Several GPUs driven from one process (the reference is one process: PathTracer.c:486-672): ranks[r] is a
+ * context that renders rank r of n_ranks of one image (ptx_render_params.rank / n_ranks / band_rows), on whatever
+ * device it was created for.  Waits for all of them and copies every context's rows, device to device, into
+ * whole-image buffers on ranks[0]'s device laid out like the reference's rgbIm and wght (PathTracer.c:550-557);
+ * the buffers belong to ranks[0] and live until its ptx_shutdown.  What a host needs before ptx_tonemap_device
+ * when it has split the image; for the host copy of the image call ptx_download on every context. */
+int ptx_gather(ptx_context *const *ranks, int n_ranks, double **d_rgb, double **d_wght);
+
 /* findFirstHit (PathTracer.c:198-251) for n rays in host memory; the ray
  * direction is used as given, as in the reference.  hits[i].obj is the
  * index into the uploaded objects[] or -1.  For triangles and rooms a and b

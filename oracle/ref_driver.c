@@ -118,41 +118,20 @@ static void finish_scene(void) {
     double pct = 0;
     for (o = light_list; o; o = o->LSnext) { o->surfaceArea = o->LSweight; pct += o->LSweight; }
     for (o = light_list; o; o = o->LSnext) o->LSweight /= pct;
-    g_flat = (struct object3D **)calloc((size_t)n + 1, sizeof(*g_flat));
-    g_nflat = 0;
 }
 
-static int count_nodes(struct BoxTree *bt) {
-    return bt ? 1 + count_nodes(bt->child1) + count_nodes(bt->child2) : 0;
-}
+/* The flat scene comes from integration/ref_flatten.c, the file a maintainer of the reference would compile into
+ * it: every comparison this harness makes with the oracle therefore also tests that file. */
+#include "../integration/ref_flatten.c"
 
-static int walk(struct BoxTree *bt, ptx_node *nodes, int *n_nodes) {
-    if (!bt) return -1;
-    int idx = (*n_nodes)++;
-    memcpy(nodes[idx].box, &bt->box, sizeof(double) * 6);
-    nodes[idx].first_obj = g_nflat;
-    for (struct object3D *o = bt->objs; o; o = o->next) {
-        o->isCSG = g_nflat;
-        g_flat[g_nflat++] = o;
-    }
-    nodes[idx].n_objs = g_nflat - nodes[idx].first_obj;
-    int c1 = walk(bt->child1, nodes, n_nodes);
-    nodes[idx].child1 = c1;
-    int c2 = walk(bt->child2, nodes, n_nodes);
-    nodes[idx].child2 = c2;
-    return idx;
-}
-
-static ptx_node *g_nodes = NULL;
-static int g_nnodes = 0;
+static ptx_scene_desc g_scene; /* of the scene built last */
 
 static void flatten_tree(void) {
-    int nn = count_nodes(boxtree);
-    free(g_nodes);
-    g_nodes = (ptx_node *)calloc((size_t)nn + 1, sizeof(ptx_node));
-    g_nnodes = 0;
+    ptx_ref_flatten_free(&g_scene);
+    free(g_flat);
+    g_flat = NULL;
     g_nflat = 0;
-    walk(boxtree, g_nodes, &g_nnodes);
+    if (ptx_ref_flatten(boxtree, light_list, cam, &g_scene, &g_flat) == 0) g_nflat = g_scene.n_objects;
 }
 
 int ref_select_scene(const char *name, int max_depth) {
@@ -213,82 +192,9 @@ int ref_build_custom(const ref_obj_spec *specs, int n, const ref_cam_spec *c, in
 int ref_num_inserted(void) { return g_ninserted; }
 
 /* ------------------------------------------------------------ scene dump */
-static int obj_type(struct object3D *o) {
-    if (o->intersect == &planeIntersect) return PTX_PLANE;
-    if (o->intersect == &sphereIntersect) return PTX_SPHERE;
-    if (o->intersect == &cylIntersect) return PTX_CYL;
-    if (o->intersect == &triangleIntersect) return PTX_TRIANGLE;
-    if (o->intersect == &cubeIntersect) return PTX_CUBE;
-    return PTX_ROOM;
-}
-
 int ref_dump_scene(const char *path) {
-    /* textures: index = position in a list built here, de-duplicated by
-     * image pointer; the doubles are turned back into the bytes they came
-     * from (value = byte / divisor, utils_path.c:1849, :1921). */
-    struct image *imgs[256];
-    int chans[256];
-    int n_img = 0;
-    ptx_object *objs = (ptx_object *)calloc((size_t)g_nflat + 1, sizeof(ptx_object));
-    for (int i = 0; i < g_nflat; i++) {
-        struct object3D *o = g_flat[i];
-        ptx_object *d = &objs[i];
-        d->type = obj_type(o);
-        d->is_light = o->isLightSource;
-        d->src_id = o->frontAndBack;
-        struct image *three[3] = {o->texImg, o->normalImg, o->alphaImg};
-        int32_t *slots[3] = {&d->tex_img, &d->normal_img, &d->alpha_img};
-        for (int k = 0; k < 3; k++) {
-            *slots[k] = -1;
-            if (!three[k]) continue;
-            int j;
-            for (j = 0; j < n_img; j++) if (imgs[j] == three[k]) break;
-            if (j == n_img) { if (n_img >= 256) return -5; imgs[n_img] = three[k]; chans[n_img] = k == 2 ? 1 : 3; n_img++; }
-            *slots[k] = j;
-        }
-        d->col[0] = o->col.R; d->col[1] = o->col.G; d->col[2] = o->col.B;
-        memcpy(d->v[0], &o->v1, 32); memcpy(d->v[1], &o->v2, 32); memcpy(d->v[2], &o->v3, 32);
-        memcpy(d->T, o->T, 128); memcpy(d->Tinv, o->Tinv, 128);
-        memcpy(d->box, &o->box, 48);
-        d->diffPct = o->diffPct; d->reflPct = o->reflPct; d->tranPct = o->tranPct;
-        d->refl_sig = o->refl_sig; d->r_index = o->r_index;
-        d->surfaceArea = o->surfaceArea; d->LSweight = o->LSweight;
-    }
-    int nl = 0;
-    for (struct object3D *o = light_list; o; o = o->LSnext) nl++;
-    int32_t *lights = (int32_t *)calloc((size_t)nl + 1, 4);
-    nl = 0;
-    for (struct object3D *o = light_list; o; o = o->LSnext) {
-        /* a light that build_boxtree dropped would not be in g_flat */
-        int idx = (o->isCSG >= 0 && o->isCSG < g_nflat && g_flat[o->isCSG] == o) ? o->isCSG : -1;
-        lights[nl++] = idx;
-    }
-    ptx_image *images = (ptx_image *)calloc((size_t)n_img + 1, sizeof(ptx_image));
-    uint64_t total = 0;
-    for (int j = 0; j < n_img; j++) total += (uint64_t)imgs[j]->sx * imgs[j]->sy * chans[j];
-    uint8_t *texels = (uint8_t *)malloc(total + 1);
-    uint64_t off = 0;
-    for (int j = 0; j < n_img; j++) {
-        uint64_t cnt = (uint64_t)imgs[j]->sx * imgs[j]->sy * chans[j];
-        const double *src = (const double *)imgs[j]->rgbdata;
-        /* every shipped texture has maxval 255 */
-        for (uint64_t k = 0; k < cnt; k++) texels[off + k] = (uint8_t)(src[k] * 255.0 + 0.5);
-        for (uint64_t k = 0; k < cnt; k++) if ((double)texels[off + k] / 255.0 != src[k]) return -6;
-        images[j].sx = imgs[j]->sx; images[j].sy = imgs[j]->sy; images[j].channels = chans[j];
-        images[j].divisor = 255.0; images[j].data_offset = off;
-        off += cnt;
-    }
-    ptx_scene_desc s;
-    memset(&s, 0, sizeof(s));
-    s.magic = PTX_SCENE_MAGIC;
-    s.n_objects = g_nflat; s.n_nodes = g_nnodes; s.n_lights = nl; s.n_images = n_img; s.n_texel_bytes = total;
-    s.objects = objs; s.nodes = g_nodes; s.lights = lights; s.images = images; s.texels = texels;
-    memcpy(s.cam.e, &cam->e, 32); memcpy(s.cam.u, &cam->u, 32); memcpy(s.cam.v, &cam->v, 32); memcpy(s.cam.w, &cam->w, 32);
-    s.cam.f = cam->f; s.cam.focus_distance = cam->focus_distance; s.cam.wl = cam->wl; s.cam.wt = cam->wt; s.cam.wsize = cam->wsize;
-    memcpy(s.cam.C2W, cam->C2W, 128); memcpy(s.cam.W2C, cam->W2C, 128);
-    int rc = ptx_scene_write(path, &s);
-    free(objs); free(lights); free(images); free(texels);
-    return rc;
+    if (g_nflat == 0) return -1;
+    return ptx_scene_write(path, &g_scene);
 }
 
 /* ------------------------------------------------------------- first hit */

@@ -405,6 +405,10 @@ __device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double
 // type) the query tested.
 struct WalkCount {
     uint32_t queries, hits, list_tests, node_visits, leaf_tests[6], texel_lookups;
+#ifdef PTX_PHASE_TIMERS
+    long long cyc_list, cyc_walk, cyc_leaf;
+    double steps_wave, leaf_passes_wave;  // loop trips as the wave sees them: every active lane adds 1/(active lanes)
+#endif
 };
 template <bool USE_BVH, bool COUNT = false>
 __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os, WalkCount *wc = nullptr) {
@@ -416,6 +420,9 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
     const double inv_dd = fast_rcp(dd);
     const ConstGeomPtr list_geom = (ConstGeomPtr)sc.list_geom;
     const PTX_CONSTANT_AS int32_t *list_ids = (const PTX_CONSTANT_AS int32_t *)sc.list_ids;
+#ifdef PTX_PHASE_TIMERS
+    long long tm0 = COUNT ? clock64() : 0;
+#endif
     for (int k = 0; k < sc.n_list; k++) {
         int part;
         const int id = USE_BVH ? list_ids[k] : k;
@@ -427,6 +434,10 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
             h.part = part;
         }
     }
+#ifdef PTX_PHASE_TIMERS
+    long long tm1 = COUNT ? clock64() : 0;
+    if (COUNT) wc->cyc_list += tm1 - tm0;
+#endif
     if (USE_BVH) {
         // slab test as b * (1/d) - p0 * (1/d): one fused multiply-add per plane.  It is less exact than
         // (b - p0) / d near b = p0, by far less than the margin the node boxes carry (ptx_bvh.h).  For a direction
@@ -442,6 +453,9 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
         while (node < n_nodes) {
             const PtxBvhNode nd = nodes[node];
             if (COUNT) wc->node_visits++;
+#ifdef PTX_PHASE_TIMERS
+            if (COUNT) wc->steps_wave += 1.0 / __popcll(__ballot(1));
+#endif
             double t0 = fma((double)nd.box[0], ix, -ox), t1 = fma((double)nd.box[1], ix, -ox);
             double t2 = fma((double)nd.box[2], iy, -oy), t3 = fma((double)nd.box[3], iy, -oy);
             double t4 = fma((double)nd.box[4], iz, -oz), t5 = fma((double)nd.box[5], iz, -oz);
@@ -455,7 +469,14 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
                 if (leaf >= 0 && id != os) {
                     int part;
                     if (COUNT) wc->leaf_tests[(leaf >> PTX_LEAF_TYPE_SHIFT) & 7]++;
+#ifdef PTX_PHASE_TIMERS
+                    if (COUNT) wc->leaf_passes_wave += 1.0 / __popcll(__ballot(1));
+                    long long tl0 = COUNT ? clock64() : 0;
+#endif
                     double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, dd, inv_dd, part);
+#ifdef PTX_PHASE_TIMERS
+                    if (COUNT) wc->cyc_leaf += clock64() - tl0;
+#endif
                     if (lam > PT_TOL && (lam < h.lambda || (lam == h.lambda && id < h.obj))) {
                         h.lambda = lam;
                         h.obj = id;
@@ -465,6 +486,9 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
             }
             node = next;
         }
+#ifdef PTX_PHASE_TIMERS
+        if (COUNT) wc->cyc_walk += clock64() - tm1;
+#endif
     }
     if (COUNT) {
         wc->queries++;
@@ -1009,6 +1033,142 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     ps.os = next_os;
     ps.depth++;
     return ps.depth > rp.max_depth;
+}
+
+// ---------------------------------------------------- PathTrace in two halves, for the kernels of large scenes
+// In a scene with a hierarchy a closest-hit query takes a different number of steps for every ray, so the render
+// kernel for such scenes does not run queries inside bounce(): every lane carries one query at a time through
+// slices of the walk (k_trace_samples_bvh), and PathTrace is cut where its queries are:
+//   shade_hit()    everything bounce() does after its first query, up to the point where the explicit light
+//                  sample needs the second one (reference PathTracer.c:285-428);
+//   apply_shadow() what follows that second query (:428-445).
+// Same operations in the same order as bounce(), so both give the same bits.
+enum { SH_END = 0, SH_NEXT = 1, SH_SHADOW = 2 };
+// What the explicit light sample keeps while its shadow query runs.
+struct ShadowPending {
+    V3 ed;          // unit direction towards the sampled light point (the shadow ray starts at the path's new p0)
+    double n_ed;    // n . ed
+    double rcp_d2;  // 1 / squared distance to the sampled point
+    double cr, cg, cb;  // throughput * surface colour, per channel
+    double inv_keep;    // 1 / (1 - RR_prob)
+};
+
+// h: result of the closest-hit query along ps.p0 + lambda * ps.d (ps.d normalised before the query, os = ps.os).
+// SH_END: the path is over, its colour is ps.I.  SH_NEXT: ps holds the next ray.  SH_SHADOW: ps holds the next
+// ray and `pend` the explicit light sample whose shadow ray (from ps.p0 along pend.ed, excluding ps.os) must be
+// resolved with apply_shadow() before the path goes on; *over is set if the path then ends (depth used up).
+template <int FLAGS>
+__device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt, const Hit &h,
+                                double &glossy, ShadowPending &pend, bool &over) {
+    glossy = 0;
+    over = false;
+    if (h.obj < 0) return SH_END;
+    const DevMat &mt = sc.mat[h.obj];
+    const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
+    V3 p, n;
+    double a, b;
+    if ((tex_img & normal_img & alpha_img) >= 0) finish_hit<true>(sc, h, ps.p0, ps.d, p, n, a, b);  // any index >= 0
+    else finish_hit<false>(sc, h, ps.p0, ps.d, p, n, a, b);
+    double R = mt.col[0], G = mt.col[1], B = mt.col[2];
+    if (tex_img >= 0) tex_map<true>(sc, tex_img, a, b, R, G, B);
+    if (normal_img >= 0) n = normal_deform<true>(sc, normal_img, a, b, n);
+    if (mt.is_light) {
+        if (!ps.cel) ps.I = mk(ps.I.x + ps.col.x * R, ps.I.y + ps.col.y * G, ps.I.z + ps.col.z * B);
+        return SH_END;
+    }
+    double rr = 0;
+    if (FLAGS & PTX_USE_RR) {
+        double mx = ps.col.x < ps.col.z ? ps.col.z : ps.col.x;  // max(max(R,B),G), reference PathTracer.c:324
+        mx = mx < ps.col.y ? ps.col.y : mx;
+        rr = 1 - mx;
+        if (rr >= .98) rr = .98;
+    }
+    if (rr > ps.rng.next()) return SH_END;
+    double diffusivity = mt.diffPct, reflectivity = mt.reflPct, transparency = mt.tranPct;
+    if (alpha_img >= 0) {
+        transparency = alpha_map(sc, alpha_img, a, b);
+        double both = reflectivity + diffusivity;
+        reflectivity = (1 - transparency) * mt.reflPct / both;
+        diffusivity = (1 - transparency) * mt.diffPct / both;
+    }
+    const double inv_keep = (FLAGS & PTX_USE_RR) ? fast_rcp(1 - rr) : 1.0;
+    double dice = ps.rng.next();
+    int next_os = h.obj;
+    int result = SH_NEXT;
+    if (dice <= diffusivity) {
+        V3 dir;
+        double scale;
+        if (FLAGS & PTX_USE_IS) {
+            dir = norm3(cos_weighted_sample(n, ps.rng));
+            scale = inv_keep;
+        } else {
+            dir = uniform_hemisphere_sample(n, ps.rng);
+            scale = dot3(n, dir) * inv_keep;
+        }
+        ps.col = mk(ps.col.x * (R * scale), ps.col.y * (G * scale), ps.col.z * (B * scale));
+        ps.p0 = p;
+        ps.d = dir;
+        if (FLAGS & PTX_USE_ES) {
+            double u = ps.rng.next();
+            int li = 0;
+            double acc = sc.lights[0].weight;
+            while (acc < u && li + 1 < sc.n_lights) {
+                li++;
+                acc += sc.lights[li].weight;
+            }
+            V3 lp = light_sample(sc.lights[li], ps.rng);
+            V3 dl = lp - p;
+            double d2 = dot3(dl, dl);
+            pend.ed = dl * fast_rsqrt(d2);
+            pend.n_ed = dot3(n, pend.ed);
+            pend.rcp_d2 = fast_rcp(d2);
+            pend.cr = ps.col.x * R;
+            pend.cg = ps.col.y * G;
+            pend.cb = ps.col.z * B;
+            pend.inv_keep = inv_keep;
+            result = SH_SHADOW;
+        }
+    } else if (dice <= diffusivity + reflectivity) {
+        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
+        n = norm3(n);
+        ps.d = reflect_dir(ps.d, n);
+        ps.p0 = p;
+        const double sig = mt.refl_sig;
+        if (sig > 0) glossy = sig;
+    } else if (dice <= diffusivity + reflectivity + transparency) {
+        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
+        refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
+        next_os = -1;
+    }
+    if (sc.has_refraction) {
+        ls.put(LS_SRCN + 0, n.x);
+        ls.put(LS_SRCN + 1, n.y);
+        ls.put(LS_SRCN + 2, n.z);
+    }
+    ps.os = next_os;
+    ps.depth++;
+    over = ps.depth > rp.max_depth;
+    return (result == SH_NEXT && over) ? SH_END : result;
+}
+
+// sh: result of the shadow query from ps.p0 along pend.ed (os = ps.os).  Reference PathTracer.c:428-445.
+__device__ inline void apply_shadow(const DevScene &sc, Path &ps, const Hit &sh, const ShadowPending &pend) {
+    int lit = 0;
+    if (sh.obj >= 0) {
+        const DevMat &lm = sc.mat[sh.obj];
+        if (lm.is_light) {
+            V3 lpnt, ln;
+            double la, lb;
+            finish_hit<false>(sc, sh, ps.p0, pend.ed, lpnt, ln, la, lb);
+            double weight2 = pend.n_ed * -dot3(ln, pend.ed);
+            double wgt = (lm.surfaceArea * weight2) * pend.rcp_d2;
+            wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
+            wgt *= pend.inv_keep;
+            ps.I = mk(ps.I.x + pend.cr * lm.col[0] * wgt, ps.I.y + pend.cg * lm.col[1] * wgt, ps.I.z + pend.cb * lm.col[2] * wgt);
+            lit = 1;
+        }
+    }
+    ps.cel = lit;
 }
 
 // The glossy perturbation d += refl_sig * (N1, N2, N3) (reference PathTracer.c:460-464) for every lane of the

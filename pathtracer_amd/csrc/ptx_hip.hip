@@ -72,6 +72,11 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
     Path ps;
     bool alive = false;
     int k = ks;
+#ifdef PTX_PHASE_TIMERS
+    WalkCount wc_dbg = {};
+    long long iters_dbg = 0;
+    const long long t_begin_dbg = clock64();
+#endif
     if (PINHOLE && inside) {
         primary_ray(sc, rp, ls, i, j, ks, ps);
         ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
@@ -86,7 +91,12 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
         }
         if (__ballot(alive) == 0ULL) break;
         double glossy = 0;
+#ifdef PTX_PHASE_TIMERS
+        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true, true>(sc, rp, ls, ps, cnt, glossy, &wc_dbg);
+        iters_dbg++;
+#else
         if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true>(sc, rp, ls, ps, cnt, glossy);
+#endif
         glossy_service(ps, glossy, lane);
         if (alive && ended) {
             // Four samples make a 128-byte line of the lane's stream.  The first three wait in LDS; the fourth goes
@@ -111,6 +121,23 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
             paths++;
         }
     }
+#ifdef PTX_PHASE_TIMERS
+    {
+        // per-lane maxima are what the wave paid: the slowest lane's cycle counts cover the whole loops
+        double v[10] = {(double)(clock64() - t_begin_dbg), (double)wc_dbg.cyc_list, (double)wc_dbg.cyc_walk, (double)iters_dbg,
+                        wc_dbg.steps_wave, wc_dbg.leaf_passes_wave, (double)wc_dbg.node_visits, (double)wc_dbg.queries, (double)wc_dbg.cyc_leaf,
+                        (double)(wc_dbg.leaf_tests[0] + wc_dbg.leaf_tests[1] + wc_dbg.leaf_tests[2] + wc_dbg.leaf_tests[3] + wc_dbg.leaf_tests[4])};
+        for (int c = 0; c < 10; c++) {
+            double m = v[c], sum = v[c];
+            for (int off = 32; off > 0; off >>= 1) {
+                m = fmax(m, __shfl_down(m, off));
+                sum += __shfl_down(sum, off);
+            }
+            const bool as_max = c < 4 || c == 8;
+            if (lane == 0) atomicAdd(&stats[PTX_STATS_WALK + c], (unsigned long long)((as_max ? m : sum) + 0.5));
+        }
+    }
+#endif
     // one set of atomics per wave
     unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
     for (int off = 32; off > 0; off >>= 1) {
@@ -310,6 +337,9 @@ struct ptx_context {
     double *d_rgb = nullptr, *d_wght = nullptr;
     bool own_accum = false;
     unsigned long long *d_stats = nullptr;
+    // whole-image buffers of ptx_gather (on the context that receives the rows), grown on demand
+    double *d_whole_rgb = nullptr, *d_whole_wght = nullptr;
+    size_t whole_pixels = 0;
 };
 
 static void free_scene(ptx_context *c) {
@@ -368,6 +398,8 @@ extern "C" void ptx_shutdown(ptx_context *c) {
     free_scene(c);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_samples);
+    (void)hipFree(c->d_whole_rgb);
+    (void)hipFree(c->d_whole_wght);
     for (hipEvent_t e : c->trace_ev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -887,6 +919,56 @@ extern "C" int ptx_download(ptx_context *c, double *rgbIm, double *wght) {
                              hipMemcpyDeviceToHost));
         local += run;
     }
+    return PTX_OK;
+}
+
+extern "C" int ptx_device_count(int *n) {
+    if (!n) return fail(PTX_EINVAL, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return PTX_OK;
+}
+
+extern "C" int ptx_gather(ptx_context *const *ranks, int n_ranks, double **d_rgb, double **d_wght) {
+    if (!ranks || n_ranks < 1 || !ranks[0]) return fail(PTX_EINVAL, "ptx_gather: no contexts");
+    ptx_context *dst = ranks[0];
+    for (int r = 0; r < n_ranks; r++) {
+        const ptx_context *c = ranks[r];
+        if (!c || !c->rendering) return fail(PTX_ESTATE, "ptx_gather: a context has no render in progress");
+        if (c->rp.sx != dst->rp.sx || c->rp.n_ranks != n_ranks || c->rp.rank != r || c->rp.band_rows != dst->rp.band_rows)
+            return fail(PTX_EINVAL, "ptx_gather: context r must render rank r of n_ranks of the same image");
+    }
+    const size_t sx = dst->rp.sx, n_pix = sx * sx;
+    HIPCHK(hipSetDevice(dst->device));
+    if (dst->whole_pixels < n_pix) {
+        (void)hipFree(dst->d_whole_rgb);
+        (void)hipFree(dst->d_whole_wght);
+        dst->d_whole_rgb = dst->d_whole_wght = nullptr;
+        dst->whole_pixels = 0;
+        HIPCHK(hipMalloc((void **)&dst->d_whole_rgb, n_pix * 3 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&dst->d_whole_wght, n_pix * sizeof(double)));
+        dst->whole_pixels = n_pix;
+    }
+    for (int r = 0; r < n_ranks; r++) {
+        ptx_context *c = ranks[r];
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));  // the rows must be final before they are copied
+        HIPCHK(hipSetDevice(dst->device));
+        const DevRender &rp = c->rp;
+        int local = 0;
+        while (local < rp.rows_owned) {  // bands of consecutive local rows are consecutive rows of the image
+            const int g0 = ptx_global_row(local, rp.rank, rp.n_ranks, rp.band_rows);
+            int run = rp.n_ranks <= 1 ? rp.rows_owned : rp.band_rows - local % rp.band_rows;
+            if (run > rp.rows_owned - local) run = rp.rows_owned - local;
+            HIPCHK(hipMemcpyPeerAsync(dst->d_whole_rgb + (size_t)g0 * sx * 3, dst->device, c->d_rgb + (size_t)local * sx * 3, c->device,
+                                      (size_t)run * sx * 3 * sizeof(double), dst->stream));
+            HIPCHK(hipMemcpyPeerAsync(dst->d_whole_wght + (size_t)g0 * sx, dst->device, c->d_wght + (size_t)local * sx, c->device,
+                                      (size_t)run * sx * sizeof(double), dst->stream));
+            local += run;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    if (d_rgb) *d_rgb = dst->d_whole_rgb;
+    if (d_wght) *d_wght = dst->d_whole_wght;
     return PTX_OK;
 }
 

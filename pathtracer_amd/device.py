@@ -19,7 +19,7 @@ EXPORTS = [
     "ptx_render_passes", "ptx_sync", "ptx_download", "ptx_accumulators", "ptx_first_hit", "ptx_first_hit_device",
     "ptx_trace_paths", "ptx_get_stats", "ptx_last_pass_ms", "ptx_last_trace_ms", "ptx_set_stream", "ptx_last_error", "ptx_version",
     "ptx_tonemap", "ptx_tonemap_device", "ptx_selftest", "ptx_upload", "ptx_last_walk_stats",
-    "ptx_render_passes_static", "ptx_static_max_pixels",
+    "ptx_render_passes_static", "ptx_static_max_pixels", "ptx_device_count", "ptx_gather",
 ]
 
 
@@ -48,6 +48,8 @@ def load_library(path=None):
     lib.ptx_render_passes.argtypes = [vp, C.c_int, C.c_int]
     lib.ptx_render_passes_static.argtypes = [vp, C.c_int, C.c_int]
     lib.ptx_static_max_pixels.restype = C.c_size_t
+    lib.ptx_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.ptx_gather.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(vp)]
     lib.ptx_sync.argtypes = [vp]
     lib.ptx_download.argtypes = [vp, vp, vp]
     lib.ptx_upload.argtypes = [vp, vp, vp]
@@ -72,6 +74,16 @@ def load_library(path=None):
 
 def make_params(sx, max_depth, flags, aperture=0.0, seed=0, rank=0, n_ranks=1, band_rows=8):
     return abi.RenderParams(sx, max_depth, flags, abi.RNG_COUNTER, aperture, seed, rank, n_ranks, band_rows, 0)
+
+
+def gather(devices):
+    """ptx_gather: the rows of devices[r] (rank r of len(devices)) collected on devices[0]'s GPU.  Returns the device
+    addresses of the whole-image rgb and weight buffers."""
+    lib = load_library()
+    arr = (C.c_void_p * len(devices))(*[d.ctx for d in devices])
+    a, b = C.c_void_p(), C.c_void_p()
+    devices[0]._check(lib.ptx_gather(arr, len(devices), C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 class Device:

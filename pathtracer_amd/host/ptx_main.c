@@ -25,16 +25,27 @@ static int die_gpu(const char *what) {
     exit(0);
 }
 
+#define PTX_MAX_GPUS 64
+
 /* dataOutput() (reference PathTracer.c:655, :661) with the tone mapping done on the GPU: same two files, same
- * bytes, same messages.  PTX_HOST_TONEMAP=1 in the environment runs the host routine instead. */
-static void output_image(ptx_context *gpu, double *rgbIm, double *wght, unsigned char *bits, int sx, char *name) {
-    if (ptx_download(gpu, rgbIm, wght) != 0) die_gpu("ptx_download");
+ * bytes, same messages.  With several contexts every one downloads its rows, and the tone mapping runs on the
+ * first context's GPU over the gathered image.  PTX_HOST_TONEMAP=1 in the environment runs the host routine
+ * instead. */
+static void output_image(ptx_context **gpu, int n_gpus, double *rgbIm, double *wght, unsigned char *bits, int sx, char *name) {
+    for (int r = 0; r < n_gpus; r++)
+        if (ptx_download(gpu[r], rgbIm, wght) != 0) die_gpu("ptx_download");
     if (getenv("PTX_HOST_TONEMAP")) {
         dataOutput(rgbIm, sx, name);
         return;
     }
     ptx_tonemap_info info;
-    if (ptx_tonemap(gpu, bits, &info) != 0) die_gpu("ptx_tonemap");
+    if (n_gpus == 1) {
+        if (ptx_tonemap(gpu[0], bits, &info) != 0) die_gpu("ptx_tonemap");
+    } else {
+        double *d_rgb = NULL;
+        if (ptx_gather(gpu, n_gpus, &d_rgb, NULL) != 0) die_gpu("ptx_gather");
+        if (ptx_tonemap_device(gpu[0], d_rgb, (uint64_t)sx * sx * 3, bits, &info) != 0) die_gpu("ptx_tonemap_device");
+    }
     ptxh_write_output(rgbIm, bits, sx, name, info.min, info.max, info.low_cut, info.high_cut);
 }
 
@@ -110,9 +121,18 @@ int main(int argc, char *argv[]) {
     printf("Focusing on plane at: (%.2f, %.2f, %.2f)\n", fp.px, fp.py, fp.pz);
     fprintf(stderr, "\n");
 
-    ptx_context *gpu = NULL;
-    if (ptx_init(0, &gpu) != 0) die_gpu("ptx_init");
-    if (ptx_scene_upload(gpu, &scene) != 0) die_gpu("ptx_scene_upload");
+    /* PTX_GPUS=N: the image rows are dealt out in bands of eight to N contexts, context r on device r modulo the
+     * number of devices (so N may exceed it).  The reference is one process on one machine's cores
+     * (PathTracer.c:620); here every GPU runs all passes for its rows and the rows are put together for output. */
+    int n_gpus = getenv("PTX_GPUS") ? atoi(getenv("PTX_GPUS")) : 1;
+    int n_devices = 0;
+    if (ptx_device_count(&n_devices) != 0 || n_devices < 1) die_gpu("ptx_device_count");
+    if (n_gpus < 1) n_gpus = 1;
+    if (n_gpus > PTX_MAX_GPUS) n_gpus = PTX_MAX_GPUS;
+    int band_rows = 8;
+    while (band_rows > 1 && (sx + band_rows - 1) / band_rows < n_gpus) band_rows /= 2;
+    if (n_gpus > sx) n_gpus = sx;
+    ptx_context *gpu[PTX_MAX_GPUS];
     ptx_render_params prm;
     memset(&prm, 0, sizeof(prm));
     prm.sx = sx;
@@ -121,9 +141,17 @@ int main(int argc, char *argv[]) {
     prm.rng_mode = PTX_RNG_COUNTER;
     prm.aperture = aperture;
     prm.seed = (uint64_t)time(NULL); /* the reference seeds drand48 from the clock too (PathTracer.c:560) */
-    prm.n_ranks = 1;
     if (getenv("PTX_SEED")) prm.seed = strtoull(getenv("PTX_SEED"), NULL, 10);
-    if (ptx_render_begin(gpu, &prm) != 0) die_gpu("ptx_render_begin");
+    prm.n_ranks = n_gpus;
+    prm.band_rows = band_rows;
+    for (int r = 0; r < n_gpus; r++) {
+        gpu[r] = NULL;
+        if (ptx_init(r % n_devices, &gpu[r]) != 0) die_gpu("ptx_init");
+        if (ptx_scene_upload(gpu[r], &scene) != 0) die_gpu("ptx_scene_upload");
+        prm.rank = r;
+        if (ptx_render_begin(gpu[r], &prm) != 0) die_gpu("ptx_render_begin");
+    }
+    if (n_gpus > 1) fprintf(stderr, "Rows in bands of %d over %d GPU contexts on %d device(s)\n", band_rows, n_gpus, n_devices);
 
     struct timespec t1, t2;
     clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -135,17 +163,27 @@ int main(int argc, char *argv[]) {
         int next_due = k % 25 == 0 ? k : k + (25 - k % 25); /* first pass index >= k whose image is written */
         int upto = next_due + 1 < num_samples ? next_due + 1 : num_samples;
         for (int q = k; q < upto; q++) fprintf(stderr, "%d/%d, ", q, num_samples);
-        if (ptx_render_passes(gpu, k, upto - k) != 0) die_gpu("ptx_render_passes");
+        for (int r = 0; r < n_gpus; r++) /* queued: the GPUs work side by side */
+            if (ptx_render_passes(gpu[r], k, upto - k) != 0) die_gpu("ptx_render_passes");
         k = upto;
-        if ((k - 1) % 25 == 0) output_image(gpu, rgbIm, wght, bits, sx, output_name);
+        if ((k - 1) % 25 == 0) output_image(gpu, n_gpus, rgbIm, wght, bits, sx, output_name);
     }
-    if (ptx_sync(gpu) != 0) die_gpu("ptx_sync");
+    for (int r = 0; r < n_gpus; r++)
+        if (ptx_sync(gpu[r]) != 0) die_gpu("ptx_sync");
     clock_gettime(CLOCK_MONOTONIC, &t2);
     fprintf(stderr, "\nDone!\n");
-    output_image(gpu, rgbIm, wght, bits, sx, output_name);
+    output_image(gpu, n_gpus, rgbIm, wght, bits, sx, output_name);
 
     ptx_stats st;
-    if (ptx_get_stats(gpu, &st) != 0) die_gpu("ptx_get_stats");
+    memset(&st, 0, sizeof(st));
+    for (int r = 0; r < n_gpus; r++) {
+        ptx_stats one;
+        if (ptx_get_stats(gpu[r], &one) != 0) die_gpu("ptx_get_stats");
+        st.paths += one.paths;
+        st.closest_hits += one.closest_hits;
+        st.shadow_rays += one.shadow_rays;
+        st.rindex_oob += one.rindex_oob;
+    }
     double secs = (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec);
     /* the reference's "rays" are paths, one per pixel sample (PathTracer.c:645) */
     fprintf(stderr, "Total number of rays created: %ld\n", (long)st.paths);
@@ -153,7 +191,7 @@ int main(int argc, char *argv[]) {
     fprintf(stderr, "Ray queries (closest hit + shadow): %ld, %f per second\n", (long)(st.closest_hits + st.shadow_rays),
             (double)(st.closest_hits + st.shadow_rays) / secs);
 
-    ptx_shutdown(gpu);
+    for (int r = 0; r < n_gpus; r++) ptx_shutdown(gpu[r]);
     ptxh_reset();
     deleteImage(im);
     free(wght);
