@@ -1171,6 +1171,79 @@ __device__ inline void apply_shadow(const DevScene &sc, Path &ps, const Hit &sh,
     ps.cel = lit;
 }
 
+// ------------------------------------------------ a closest-hit query carried in slices
+// The same query as closest_hit_all<true>, cut into pieces a kernel can interleave with other work: the lanes of a
+// wave need very different numbers of steps for their rays, and a wave that runs whole queries waits for its
+// slowest ray twice per bounce.
+//   query_begin()  the always-tested list and the constants of the walk
+//   query_step()   one node of the hierarchy; a leaf whose box the ray enters is not tested at once but noted in
+//                  Query::leaf (the lane then pauses), so that a wave can test the leaves of many lanes together
+//   query_leaf()   the primitive test of the noted leaf
+// The query is over when node >= sc.n_bvh_nodes and leaf < 0.  The closest hit, ties included, does not depend on
+// the order of the tests, so the result has the bits closest_hit_all gives.
+struct Query {
+    double ix, iy, iz, ox, oy, oz;  // slab test: t = bound * i - o
+    Hit h;
+    int node;  // next node to visit, relative to the start of the octant's array
+    int base;  // where that array starts in sc.bvh
+    int leaf;  // >= 0: PtxBvhNode::obj of a leaf waiting for its primitive test
+};
+__device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int os, Query &q) {
+    q.h.lambda = INFINITY;
+    q.h.obj = -1;
+    q.h.part = 0;
+    const double dd = dot3(d, d);
+    const double inv_dd = fast_rcp(dd);
+    const ConstGeomPtr list_geom = (ConstGeomPtr)sc.list_geom;
+    const PTX_CONSTANT_AS int32_t *list_ids = (const PTX_CONSTANT_AS int32_t *)sc.list_ids;
+    for (int k = 0; k < sc.n_list; k++) {
+        int part;
+        const int id = list_ids[k];
+        double lam = isect_any(list_geom + k, p0, d, dd, inv_dd, part);
+        if (id != os && lam > PT_TOL && lam < q.h.lambda) {
+            q.h.lambda = lam;
+            q.h.obj = id;
+            q.h.part = part;
+        }
+    }
+    q.ix = rcp_for_slab(d.x);
+    q.iy = rcp_for_slab(d.y);
+    q.iz = rcp_for_slab(d.z);
+    q.ox = p0.x * q.ix;
+    q.oy = p0.y * q.iy;
+    q.oz = p0.z * q.iz;
+    const int octant = sc.bvh_per_octant ? ((d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2) : 0;
+    q.base = octant * sc.n_bvh_nodes;
+    q.node = 0;
+    q.leaf = -1;
+}
+// Free of branches, and the node fetched as two 16-byte words whatever the outcome of the box test.
+__device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q) {
+    const float4 *np = (const float4 *)(sc.bvh + (size_t)(uint32_t)(q.base + q.node));
+    const float4 lo = np[0], hi = np[1];  // box[0..3]; box[4], box[5], skip, obj
+    double t0 = fma((double)lo.x, q.ix, -q.ox), t1 = fma((double)lo.y, q.ix, -q.ox);
+    double t2 = fma((double)lo.z, q.iy, -q.oy), t3 = fma((double)lo.w, q.iy, -q.oy);
+    double t4 = fma((double)hi.x, q.iz, -q.oz), t5 = fma((double)hi.y, q.iz, -q.oz);
+    double lmin = fmax(fmax(fmin(t0, t1), fmin(t2, t3)), fmin(t4, t5));
+    double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
+    const int skip = __float_as_int(hi.z), obj = __float_as_int(hi.w);
+    const bool enter = !(lmin > lmax) && !(lmax < 0) && !(lmin > q.h.lambda);
+    q.leaf = (enter && obj >= 0 && (obj & PTX_LEAF_INDEX) != os) ? obj : -1;
+    q.node = enter ? q.node + 1 : skip;
+}
+__device__ __forceinline__ void query_leaf(const DevScene &sc, V3 p0, V3 d, Query &q) {
+    const int leaf = q.leaf, id = leaf & PTX_LEAF_INDEX;
+    const double dd = dot3(d, d);
+    int part;
+    double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, dd, fast_rcp(dd), part);
+    if (lam > PT_TOL && (lam < q.h.lambda || (lam == q.h.lambda && id < q.h.obj))) {
+        q.h.lambda = lam;
+        q.h.obj = id;
+        q.h.part = part;
+    }
+    q.leaf = -1;
+}
+
 // The glossy perturbation d += refl_sig * (N1, N2, N3) (reference PathTracer.c:460-464) for every lane of the
 // wave that asked for it, to be called by all 64 lanes together.  Few lanes reflect off a glossy surface in any
 // one bounce, and each needs three independent deviates (a log, a cos and a square root apiece), so the deviates

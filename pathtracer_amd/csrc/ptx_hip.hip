@@ -154,6 +154,279 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
     }
 }
 
+// The tracing kernel for scenes with a hierarchy.  Same tiles, sample ranges and sample buffer as k_trace_samples,
+// but a lane does not run whole closest-hit queries: it carries one query (of a path segment or of a shadow ray)
+// at a time through the walk (query_begin / query_step / query_leaf), and the loop alternates between
+//   walking  -- every lane with an unfinished query visits hierarchy nodes, until at most exit_lanes lanes are
+//               still walking and there is something to shade; a ray that needs thirty steps no longer keeps
+//               sixty-three rays that needed five waiting, it simply goes on in the next walking phase;
+//   shading  -- the lanes whose query has finished take its result.  Resolving a shadow ray (apply_shadow) is
+//               cheap and done whenever one is ready; the surface interaction (shade_hit) is a few thousand
+//               instructions that the wave pays for whatever the number of lanes in it, so it waits until
+//               shade_min lanes have a closest hit to shade (or nothing else can make progress).  Most lanes thus
+//               still move in step -- query, shade, shadow query, resolve -- and only the stragglers drift.
+// Leaves are not tested where they are met: a lane pauses at a leaf whose box it enters, and the wave tests the
+// leaves of leaf_batch lanes together (or of those there are, when no lane can step).
+// Work is handed out while the kernel runs.  A work tile is what a wave of k_trace_samples traces, sub_len samples
+// of the 64 pixels of a tile; here the waves are persistent (the grid is what the GPU holds at once), a wave takes
+// the next work tile from a counter in device memory (*work_counter, zero at launch) whenever its lanes have used
+// up the pixels of the last one, and a lane that has finished its pixel's samples takes any pixel of the wave's
+// current work tile that has not been handed out.  Paths differ much in length (a pixel's 25 samples take between
+// half and twice the average number of queries), and with fixed pixels a wave ends up waiting for its slowest
+// pixel with most lanes idle; this way every lane has work until the image runs out.
+// Every path performs the operations of bounce() in the same order, so the image has the same bits.
+template <int FLAGS, bool PINHOLE>
+__global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_per_simd))
+    k_trace_samples_bvh(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, int n_work, size_t stride,
+                        double *__restrict__ samples, unsigned long long *__restrict__ stats, unsigned int *__restrict__ work_counter,
+                        int exit_lanes, int leaf_batch, int shade_min, int burst) {
+    enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
+    __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
+    __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
+    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (rp.sx + 7) >> 3;
+    const int n_nodes = sc.n_bvh_nodes;
+    // the lane's pixel and sample range (none yet: k == ke)
+    int i = 0, j = 0, ks = 0, ke = 0, k = 0;
+    size_t pix = 0;
+    // the wave's current work tile and which of its pixels have not been handed out; both the same in every lane
+    int cur_tile = 0, cur_sub = 0;
+    unsigned long long cur_free = 0ULL;
+    bool exhausted = false;  // the counter has run past the last work tile
+
+    enum { M_NONE = 0, M_CLOSEST = 1, M_SHADOW = 2 };
+    Counters cnt = {0, 0, 0};
+    uint32_t paths = 0;
+    Path ps;
+    ShadowPending pend;
+    Query q;
+#ifdef PTX_PHASE_TIMERS
+    // per wave: cycles spent in each part of the loop, how often it ran and with how many lanes
+    enum { D_TOTAL, D_SHADE, D_SHADOW, D_SETUP, D_STEPS, D_LEAF, D_REGEN, D_N_ITER, D_N_SHADE, D_L_SHADE, D_N_SHADOW, D_L_SHADOW,
+           D_N_SETUP, D_L_SETUP, D_N_BURST, D_L_BURST, D_N_LEAF, D_L_LEAF, D_N_REGEN, D_L_REGEN, D_L_STEPS, D_L_ACTIVE };
+    unsigned long long dbg[PTX_N_DBG] = {};
+    const long long dbg_t0 = clock64();
+    long long dbg_t;
+#define DBG_BEGIN() (dbg_t = clock64())
+#define DBG_END(slot_cyc, slot_n, slot_l, pred)                 \
+    do {                                                        \
+        dbg[slot_cyc] += (unsigned long long)(clock64() - dbg_t); \
+        dbg[slot_n] += 1;                                       \
+        dbg[slot_l] += __popcll(__ballot(pred));                \
+    } while (0)
+#else
+#define DBG_BEGIN() ((void)0)
+#define DBG_END(a, b, c, d) ((void)0)
+#endif
+    q.node = n_nodes;
+    q.leaf = -1;
+    int mode = M_NONE;   // what the lane's query is for
+    bool fresh = false;  // the query has yet to be set up
+    bool over = false;   // M_SHADOW: the path ends when the shadow ray is resolved
+    for (;;) {
+        // ---- shading: lanes whose query is over
+        bool ended = false;
+        {
+            const bool ready = mode != M_NONE && !fresh && q.node >= n_nodes && q.leaf < 0;
+            const bool ready_closest = ready && mode == M_CLOSEST;
+            const int n_closest = __popcll(__ballot(ready_closest));
+            const int n_busy = __popcll(__ballot(mode != M_NONE && !ready));
+            const int n_active = __popcll(__ballot(mode != M_NONE));
+            const bool ready_shadow = ready && mode == M_SHADOW;
+            if (__ballot(ready_shadow) != 0ULL) {
+                DBG_BEGIN();
+                if (ready_shadow) {
+                    apply_shadow(sc, ps, q.h, pend);
+                    ended = over;
+                    mode = M_CLOSEST;
+                    fresh = true;
+                }
+                DBG_END(D_SHADOW, D_N_SHADOW, D_L_SHADOW, ready_shadow);
+            }
+            if (n_closest > 0 && (64 * n_closest >= shade_min * n_active || n_busy == 0)) {
+                DBG_BEGIN();
+                double glossy = 0;
+                if (ready_closest) {
+                    const int r = shade_hit<FLAGS>(sc, rp, ls, ps, cnt, q.h, glossy, pend, over);
+                    ended = r == SH_END;
+                    mode = r == SH_SHADOW ? M_SHADOW : M_CLOSEST;
+                    fresh = true;
+                }
+                glossy_service(ps, glossy, lane);
+                DBG_END(D_SHADE, D_N_SHADE, D_L_SHADE, ready_closest);
+            }
+        }
+#ifdef PTX_PHASE_TIMERS
+        dbg[D_N_ITER]++;
+        dbg[D_L_ACTIVE] += __popcll(__ballot(mode != M_NONE || k < ke || !exhausted));
+        const bool dbg_regen = ended || (mode == M_NONE && k < ke);
+#endif
+        DBG_BEGIN();
+        if (ended) {
+            // four samples make a 128-byte line of the lane's stream, written once and whole (see k_trace_samples)
+            const int slot = (k - ks) & 3;
+            double4 *out = (double4 *)(samples + (pix * stride + (size_t)(k - k0)) * PTX_SAMPLE_DOUBLES);
+            if (slot == 3) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    out[c - 3] = make_double4(ls.get(LS_PARKED + 3 * c), ls.get(LS_PARKED + 3 * c + 1), ls.get(LS_PARKED + 3 * c + 2), 0.0);
+                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
+            } else if (k + (3 - slot) >= ke) {
+                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
+            } else {
+                ls.put(LS_PARKED + 3 * slot, ps.I.x);
+                ls.put(LS_PARKED + 3 * slot + 1, ps.I.y);
+                ls.put(LS_PARKED + 3 * slot + 2, ps.I.z);
+            }
+            mode = M_NONE;
+            fresh = false;
+            k++;
+            paths++;
+        }
+        // ---- a new pixel for the lanes that have done theirs
+        for (;;) {
+            const bool need = mode == M_NONE && k >= ke;
+            const unsigned long long m_need = __ballot(need);
+            if (m_need == 0ULL) break;
+            if (cur_free == 0ULL) {
+                if (exhausted) break;
+                unsigned int wt = 0;
+                if (lane == 0) wt = atomicAdd(work_counter, 1u);
+                wt = __shfl(wt, 0);
+                if (wt >= (unsigned int)n_work) {
+                    exhausted = true;
+                    break;
+                }
+                cur_tile = (int)(wt % (unsigned int)n_tiles);
+                cur_sub = (int)(wt / (unsigned int)n_tiles);
+                const int tx = cur_tile % tiles_x, ty = cur_tile / tiles_x;
+                cur_free = __ballot(tx * 8 + (lane & 7) < rp.sx && ty * 8 + (lane >> 3) < rp.rows_owned);
+                continue;
+            }
+            // the r-th lane in need takes the r-th free pixel
+            const int r = __popcll(m_need & ((1ULL << lane) - 1ULL));
+            const int n_free = __popcll(cur_free), n_need = __popcll(m_need);
+            if (need && r < n_free) {
+                int pos = 0, left = r;  // position of the r-th set bit of cur_free
+#pragma unroll
+                for (int w = 32; w >= 1; w >>= 1) {
+                    const int c = __popcll((cur_free >> pos) & ((1ULL << w) - 1ULL));
+                    if (left >= c) {
+                        left -= c;
+                        pos += w;
+                    }
+                }
+                const int tx = cur_tile % tiles_x, ty = cur_tile / tiles_x;
+                i = tx * 8 + (pos & 7);
+                const int jl = ty * 8 + (pos >> 3);
+                j = ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows);
+                pix = (size_t)jl * rp.sx + i;
+                ks = k0 + cur_sub * sub_len;
+                ke = ks + sub_len < k1 ? ks + sub_len : k1;
+                k = ks;
+                if (PINHOLE) {
+                    primary_ray(sc, rp, ls, i, j, ks, ps);
+                    ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
+                }
+            }
+            // drop the pixels just handed out: the lowest min(n_need, n_free) set bits
+            const int taken = n_need < n_free ? n_need : n_free;
+            unsigned long long rest = cur_free;
+            for (int t = 0; t < taken; t++) rest &= rest - 1ULL;
+            cur_free = rest;
+        }
+        // ---- a pixel's next sample
+        if (mode == M_NONE && k < ke) {
+            if (PINHOLE) primary_ray_cached(sc, rp, ls, i, j, k, ps);
+            else primary_ray(sc, rp, ls, i, j, k, ps);
+            if (rp.max_depth < 1) {  // reference PathTracer.c:273 with depth = 1: the path is over before its first query
+                mode = M_SHADOW;
+                over = true;
+                q.h.obj = -1;
+            } else {
+                mode = M_CLOSEST;
+                fresh = true;
+            }
+        }
+        DBG_END(D_REGEN, D_N_REGEN, D_L_REGEN, dbg_regen);
+        if (__ballot(mode != M_NONE) == 0ULL) break;
+        // ---- the next query of the lanes that have one: the primitives every ray tests
+        DBG_BEGIN();
+#ifdef PTX_PHASE_TIMERS
+        const bool dbg_fresh = fresh;
+#endif
+        if (fresh) {
+            V3 qd;
+            if (mode == M_CLOSEST) {
+                ps.d = norm3(ps.d);
+                cnt.closest++;
+                qd = ps.d;
+            } else {
+                cnt.shadow++;
+                qd = pend.ed;
+            }
+            query_begin(sc, ps.p0, qd, ps.os, q);
+            fresh = false;
+        }
+        DBG_END(D_SETUP, D_N_SETUP, D_L_SETUP, dbg_fresh);
+        // ---- walking: bursts of up to `burst` steps per lane, with the wave-level decisions in between
+        const int n_active = __popcll(__ballot(mode != M_NONE));
+        for (;;) {
+            DBG_BEGIN();
+#ifdef PTX_PHASE_TIMERS
+            const bool dbg_walking = q.leaf < 0 && q.node < n_nodes;
+            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) {
+                query_step(sc, ps.os, q);
+                dbg[D_L_STEPS]++;
+            }
+#else
+            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) query_step(sc, ps.os, q);
+#endif
+            DBG_END(D_STEPS, D_N_BURST, D_L_BURST, dbg_walking);
+            const bool paused = q.leaf >= 0;
+            const bool stepping = !paused && q.node < n_nodes;
+            const int n_step = __popcll(__ballot(stepping)), n_paused = __popcll(__ballot(paused));
+            if (n_paused > 0 && (n_paused >= leaf_batch || n_step == 0)) {
+                DBG_BEGIN();
+                if (paused) query_leaf(sc, ps.p0, mode == M_SHADOW ? pend.ed : ps.d, q);
+                DBG_END(D_LEAF, D_N_LEAF, D_L_LEAF, paused);
+                continue;
+            }
+            if (n_step == 0) break;
+            if (n_step + n_paused <= exit_lanes) {
+                const bool done = mode != M_NONE && !stepping && !paused;
+                const int n_closest = __popcll(__ballot(done && mode == M_CLOSEST));
+                if (64 * n_closest >= shade_min * n_active || __ballot(done && mode == M_SHADOW) != 0ULL) break;
+            }
+        }
+    }
+    #ifdef PTX_PHASE_TIMERS
+    dbg[D_TOTAL] = (unsigned long long)(clock64() - dbg_t0);
+    for (int c = 0; c < PTX_N_DBG; c++) {
+        // cycle counts and invocation counts are the same in every lane; D_L_STEPS is per lane
+        unsigned long long v = dbg[c];
+        if (c == D_L_STEPS)
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && v) atomicAdd(&stats[PTX_STATS_DBG + c], v);
+    }
+#endif
+    // one set of atomics per wave
+    unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off);
+        c1 += __shfl_down(c1, off);
+        c2 += __shfl_down(c2, off);
+        c3 += __shfl_down(c3, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&stats[0], c0);
+        atomicAdd(&stats[1], c1);
+        atomicAdd(&stats[2], c2);
+        if (c3) atomicAdd(&stats[3], c3);
+    }
+}
+
 // One sample folded into a pixel's accumulator (reference PathTracer.c:646-652)
 __device__ __forceinline__ void fold_sample(double &ar, double &ag, double &ab, double &wt, double cr, double cg, double cb) {
     const double f = exp2(-lean_log(wt));
@@ -743,6 +1016,16 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     // short enough runs that a slow tile does not hold the end of the launch (measured best between 16 and 32)
     long fill = 16;
     if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
+    // Scenes with a hierarchy: the kernel that carries queries in slices (PTX_BVH_KERNEL=whole selects the kernel
+    // that runs whole queries, for comparisons; the images are the same).  Its two settings were swept on SciFiCube
+    // and BubbleTea: leave the walk when at most exit_lanes lanes are still in it, test leaves leaf_batch at a time.
+    bool sliced = true;
+    if (const char *e = getenv("PTX_BVH_KERNEL")) sliced = strcmp(e, "whole") != 0;
+    int exit_lanes = 8, leaf_batch = 4, shade_min = 40, burst = 8;
+    if (const char *e = getenv("PTX_WALK_EXIT_LANES")) exit_lanes = std::max(0, std::min(63, atoi(e)));
+    if (const char *e = getenv("PTX_WALK_LEAF_BATCH")) leaf_batch = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("PTX_WALK_SHADE_MIN")) shade_min = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("PTX_WALK_BURST")) burst = std::max(1, atoi(e));
     c->n_trace_launches = 0;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int ka = k0; ka < k0 + nk; ka += round_max) {
@@ -760,11 +1043,24 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
             }
             HIPCHK(hipEventRecord(c->trace_ev[2 * c->n_trace_launches], c->stream));
         }
+        unsigned int *work_counter = (unsigned int *)(c->d_stats + PTX_STATS_WORK);
+        if (c->use_bvh && sliced) HIPCHK(hipMemsetAsync(work_counter, 0, sizeof(unsigned long long), c->stream));
         dispatch_flags(c->prm.flags, c->use_bvh, [&](auto fl, auto bv) {
             constexpr int F = decltype(fl)::value;
             constexpr bool B = decltype(bv)::value;
             const dim3 grid((unsigned)(n_tiles * n_sub));
-            if (pinhole)
+            // persistent waves: as many as the GPU holds at once, or as there are work tiles
+            const dim3 pgrid((unsigned)std::min<long>(n_tiles * n_sub, slots));
+            if (B && sliced) {
+                if (pinhole)
+                    hipLaunchKernelGGL((k_trace_samples_bvh<F, true>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
+                                       sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
+                                       exit_lanes, leaf_batch, shade_min, burst);
+                else
+                    hipLaunchKernelGGL((k_trace_samples_bvh<F, false>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
+                                       sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
+                                       exit_lanes, leaf_batch, shade_min, burst);
+            } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                    sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
             else
@@ -1002,6 +1298,15 @@ extern "C" int ptx_get_stats(ptx_context *c, ptx_stats *st) {
     unsigned long long h[4];
     HIPCHK(hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     st->paths = h[0]; st->closest_hits = h[1]; st->shadow_rays = h[2]; st->rindex_oob = h[3];
+    return PTX_OK;
+}
+
+extern "C" int ptx_debug_counters(ptx_context *c, unsigned long long *out, int clear) {
+    if (!c || !out) return fail(PTX_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_stats + PTX_STATS_DBG, PTX_N_DBG * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (clear) HIPCHK(hipMemset(c->d_stats + PTX_STATS_DBG, 0, PTX_N_DBG * sizeof(unsigned long long)));
     return PTX_OK;
 }
 

@@ -407,6 +407,34 @@ def test_hierarchy_order_does_not_change_results(name, scenes, monkeypatch):
     assert a[3]["paths"] == b[3]["paths"] and a[3]["closest_hits"] == b[3]["closest_hits"]
 
 
+@pytest.mark.parametrize("name,ap", [("scifi", 0.05), ("scifi", 0.0), ("bubbletea", 0.15)])
+def test_sliced_queries_do_not_change_results(name, ap, gpu, monkeypatch):
+    """Hierarchy scenes are rendered by the kernel that carries closest-hit queries in slices and hands pixels out
+    while it runs; PTX_BVH_KERNEL=whole selects the kernel that runs whole queries with fixed pixels.  Every path
+    performs the same operations either way, so images and counters are equal bit for bit, whatever the settings of
+    the sliced kernel (when it leaves the walk, how many leaves it tests together, when it shades, steps per burst),
+    on an image with partial tiles, with all sampling switches and with none, and at depths 0 and 1."""
+    dev = gpu[name]
+    for sx, depth, flags, spp in ((52, 12, ALL, 6), (52, 12, 0, 3), (40, 1, ALL, 5), (24, 0, ALL, 4)):
+        prm = pt.make_params(sx, depth, flags, ap, seed=5)
+        got = []
+        for kernel, settings in (("whole", None), ("sliced", None), ("sliced", ("0", "1", "64", "1")), ("sliced", ("63", "64", "1", "3")),
+                                 ("sliced", ("20", "7", "33", "100"))):
+            monkeypatch.setenv("PTX_BVH_KERNEL", kernel)
+            for var, val in zip(("PTX_WALK_EXIT_LANES", "PTX_WALK_LEAF_BATCH", "PTX_WALK_SHADE_MIN", "PTX_WALK_BURST"), settings or (None,) * 4):
+                if val is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, val)
+            dev.render_begin(prm)
+            dev.render_passes(0, spp)
+            rgb, w = dev.download()
+            got.append((rgb, w, dev.stats()))
+        assert got[0][2]["paths"] == sx * sx * spp
+        for rgb, w, st in got[1:]:
+            assert np.array_equal(rgb, got[0][0], equal_nan=True) and np.array_equal(w, got[0][1], equal_nan=True) and st == got[0][2]
+
+
 def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
     """A render_passes call traces its samples in as many rounds as the sample buffer needs and cuts each round
     into waves of whatever length fills the GPU; the accumulator is folded in sample order all the same, so the

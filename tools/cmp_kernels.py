@@ -1,3 +1,5 @@
+"""Times the render kernels for hierarchy scenes against each other and checks that their images are equal.
+usage: cmp_kernels.py size spp [whole | sliced[:exit_lanes,leaf_batch,shade_min,burst]] ..."""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +16,8 @@ for name, depth, ap in (("scifi", 12, 0.05), ("bubbletea", 12, 0.15)):
     for v in variants:
         kern, _, rest = v.partition(":")
         os.environ["PTX_BVH_KERNEL"] = kern
-        if rest:
-            e, b = rest.split(",")
-            os.environ["PTX_WALK_EXIT_LANES"] = e; os.environ["PTX_WALK_LEAF_BATCH"] = b
+        for var, val in zip(("PTX_WALK_EXIT_LANES", "PTX_WALK_LEAF_BATCH", "PTX_WALK_SHADE_MIN", "PTX_WALK_BURST"), rest.split(",") if rest else ()):
+            os.environ[var] = val
         prm = pt.make_params(size, depth, 7, ap, seed=3)
         dev.render_begin(prm); dev.render_passes(0, 4); dev.sync()  # warm
         dev.render_begin(prm)
