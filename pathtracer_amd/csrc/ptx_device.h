@@ -158,6 +158,8 @@ struct DevCamera {
     double fp[3];  // C2W * (0,0,focus_distance,1), reference PathTracer.c:589-594
 };
 
+// Groups of the always-tested primitives by intersection routine
+enum { LC_FAST_SPHERE = 0, LC_SPHERE, LC_PLANE, LC_TRIANGLE, LC_CYL, LC_BOX, LC_N };
 // Closest-hit queries test two sets of primitives: a short list that every ray tests in turn (all primitives of a
 // small scene; in a large scene the few whose boxes are far bigger than the rest, which would spoil a hierarchy),
 // and the remaining primitives through the bounding-volume hierarchy.
@@ -174,6 +176,9 @@ struct DevScene {
     int32_t bvh_per_octant;                  // 1: bvh holds eight arrays, one per octant of ray directions
     int32_t n_lights, n_images, has_refraction;
     DevCamera cam;
+    const DevGeom *class_geom;  // the always-tested primitives grouped by intersection routine (LC_*), ascending scene
+    const int32_t *class_ids;   // index within a group, and their scene indices
+    int32_t class_end[6];       // where each group ends in class_geom
 };
 
 struct DevRender {
@@ -316,6 +321,9 @@ __device__ __forceinline__ double isect_box(MP m, V3 p0, V3 d, int &part) {
 }
 
 // cylIntersect, reference utils_path.c:625-779.  part: 0 wall, 1 z=-1 cap, 2 z=+1 cap.
+// The reference's four divisions are multiplications by reciprocals here.  Where it divides by zero (a ray along
+// the axis for the wall, a ray across the axis for the caps) its quotients are infinite or NaN and every test on
+// them fails; fast_rcp(0) is NaN, and the tests fail the same way.
 template <typename MP>
 __device__ __forceinline__ double isect_cyl(MP m, V3 p0, V3 d, int &part) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
@@ -326,14 +334,15 @@ __device__ __forceinline__ double isect_cyl(MP m, V3 p0, V3 d, int &part) {
     double C = tp.x * tp.x + tp.y * tp.y - 1;
     double det = B * B - 4 * A * C;
     if (!(det < 0)) {
-        double sq = sqrt(det);
-        double l1 = (-1 * B + sq) / (2 * A);
-        double l2 = (-1 * B - sq) / (2 * A);
+        const double sq = fast_sqrt(det), inv_2a = fast_rcp(2 * A);
+        double l1 = (-1 * B + sq) * inv_2a;
+        double l2 = (-1 * B - sq) * inv_2a;
         if (fabs(tp.z + l1 * td.z) <= 1 && l1 > PT_TOL && best > l1) { best = l1; part = 0; }
         if (fabs(tp.z + l2 * td.z) <= 1 && l2 > PT_TOL && best > l2) { best = l2; part = 0; }
     }
-    double c1 = (-1 - tp.z) / td.z;
-    double c2 = (1 - tp.z) / td.z;
+    const double inv_dz = fast_rcp(td.z);
+    double c1 = (-1 - tp.z) * inv_dz;
+    double c2 = (1 - tp.z) * inv_dz;
     {
         double x = tp.x + c1 * td.x, y = tp.y + c1 * td.y;
         if (x * x + y * y <= 1 && c1 > PT_TOL && best > c1) { best = c1; part = 1; }
@@ -1194,17 +1203,37 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
     q.h.part = 0;
     const double dd = dot3(d, d);
     const double inv_dd = fast_rcp(dd);
-    const ConstGeomPtr list_geom = (ConstGeomPtr)sc.list_geom;
-    const PTX_CONSTANT_AS int32_t *list_ids = (const PTX_CONSTANT_AS int32_t *)sc.list_ids;
-    for (int k = 0; k < sc.n_list; k++) {
-        int part;
-        const int id = list_ids[k];
-        double lam = isect_any(list_geom + k, p0, d, dd, inv_dd, part);
-        if (id != os && lam > PT_TOL && lam < q.h.lambda) {
+    // The always-tested primitives, group by group: a loop that knows its intersection routine asks for the part
+    // of the record it needs without first waiting for the record's type (the records arrive by scalar loads, and
+    // a wave has little else to do while it waits for one).  Equal lambdas go to the lower scene index, as in
+    // closest_hit_all, where the primitives are tested in that order.
+    const ConstGeomPtr cg = (ConstGeomPtr)sc.class_geom;
+    const PTX_CONSTANT_AS int32_t *ids = (const PTX_CONSTANT_AS int32_t *)sc.class_ids;
+    auto take = [&](int id, double lam, int part) {
+        if (id != os && lam > PT_TOL && (lam < q.h.lambda || (lam == q.h.lambda && id < q.h.obj))) {
             q.h.lambda = lam;
             q.h.obj = id;
             q.h.part = part;
         }
+    };
+    int k = 0;
+    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform(cg + k, p0, d, dd, inv_dd), 0);
+    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere(&cg[k].m[0], p0, d), 0);
+    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane(&cg[k].m[0], p0, d), 0);
+    for (; k < sc.class_end[LC_TRIANGLE]; k++) {
+        int part;
+        const double lam = isect_triangle(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
+    }
+    for (; k < sc.class_end[LC_CYL]; k++) {
+        int part;
+        const double lam = isect_cyl(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
+    }
+    for (; k < sc.class_end[LC_BOX]; k++) {
+        int part;
+        const double lam = isect_box(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
     }
     q.ix = rcp_for_slab(d.x);
     q.iy = rcp_for_slab(d.y);

@@ -42,6 +42,9 @@ struct TraceShape {
     static constexpr int waves_per_simd = (USE_BVH || !PINHOLE) ? 3 : 4;
 };
 
+#ifndef PTX_BVH_WAVES
+#define PTX_BVH_WAVES 3
+#endif
 // One lane per pixel of the tile; a lane starts its pixel's next sample as soon as its path ends (path
 // regeneration), so the wave stays full until its slowest pixel is done with the range.
 // PINHOLE: the aperture is zero, so every sample of a pixel starts along the same direction.
@@ -176,10 +179,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
 // pixel with most lanes idle; this way every lane has work until the image runs out.
 // Every path performs the operations of bounce() in the same order, so the image has the same bits.
 template <int FLAGS, bool PINHOLE>
-__global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_per_simd))
+__global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     k_trace_samples_bvh(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, int n_work, size_t stride,
                         double *__restrict__ samples, unsigned long long *__restrict__ stats, unsigned int *__restrict__ work_counter,
-                        int exit_lanes, int leaf_batch, int shade_min, int burst) {
+                        int exit_lanes, int leaf_batch, int shade_min, int burst, int small_run) {
     enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
     __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
@@ -227,6 +230,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
     for (;;) {
         // ---- shading: lanes whose query is over
         bool ended = false;
+        bool shaded = false;  // shade_hit ran in this iteration
         {
             const bool ready = mode != M_NONE && !fresh && q.node >= n_nodes && q.leaf < 0;
             const bool ready_closest = ready && mode == M_CLOSEST;
@@ -234,7 +238,9 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
             const int n_busy = __popcll(__ballot(mode != M_NONE && !ready));
             const int n_active = __popcll(__ballot(mode != M_NONE));
             const bool ready_shadow = ready && mode == M_SHADOW;
-            if (__ballot(ready_shadow) != 0ULL) {
+            const bool shade_now = n_closest > 0 && (64 * n_closest >= shade_min * n_active || n_busy == 0);
+            const int n_shadow = __popcll(__ballot(ready_shadow));
+            if (n_shadow > 0 && (n_shadow >= small_run || shade_now || n_busy == 0)) {
                 DBG_BEGIN();
                 if (ready_shadow) {
                     apply_shadow(sc, ps, q.h, pend);
@@ -244,7 +250,8 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
                 }
                 DBG_END(D_SHADOW, D_N_SHADOW, D_L_SHADOW, ready_shadow);
             }
-            if (n_closest > 0 && (64 * n_closest >= shade_min * n_active || n_busy == 0)) {
+            shaded = shade_now;
+            if (shade_now) {
                 DBG_BEGIN();
                 double glossy = 0;
                 if (ready_closest) {
@@ -336,8 +343,11 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
             for (int t = 0; t < taken; t++) rest &= rest - 1ULL;
             cur_free = rest;
         }
-        // ---- a pixel's next sample
-        if (mode == M_NONE && k < ke) {
+        // ---- a pixel's next sample (not for a few lanes at a time: they wait for the iteration in which the others
+        // have been shaded, unless the wave has nothing else to do)
+        const int n_start = __popcll(__ballot(mode == M_NONE && k < ke));
+        const bool start_now = n_start >= small_run || shaded || __ballot(mode != M_NONE && (fresh || q.node < n_nodes || q.leaf >= 0)) == 0ULL;
+        if (start_now && mode == M_NONE && k < ke) {
             if (PINHOLE) primary_ray_cached(sc, rp, ls, i, j, k, ps);
             else primary_ray(sc, rp, ls, i, j, k, ps);
             if (rp.max_depth < 1) {  // reference PathTracer.c:273 with depth = 1: the path is over before its first query
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
             }
         }
         DBG_END(D_REGEN, D_N_REGEN, D_L_REGEN, dbg_regen);
-        if (__ballot(mode != M_NONE) == 0ULL) break;
+        if (__ballot(mode != M_NONE || k < ke) == 0ULL) break;
         // ---- the next query of the lanes that have one: the primitives every ray tests
         DBG_BEGIN();
 #ifdef PTX_PHASE_TIMERS
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<true, PINHOLE>::waves_p
             if (n_step + n_paused <= exit_lanes) {
                 const bool done = mode != M_NONE && !stepping && !paused;
                 const int n_closest = __popcll(__ballot(done && mode == M_CLOSEST));
-                if (64 * n_closest >= shade_min * n_active || __ballot(done && mode == M_SHADOW) != 0ULL) break;
+                if (64 * n_closest >= shade_min * n_active || __popcll(__ballot(done && mode == M_SHADOW)) >= small_run) break;
             }
         }
     }
@@ -600,7 +610,7 @@ struct ptx_context {
     bool have_scene = false;
     DevScene sc{};
     void *d_geom = nullptr, *d_mat = nullptr, *d_lights = nullptr, *d_images = nullptr, *d_texels = nullptr;
-    void *d_list_geom = nullptr, *d_list_ids = nullptr, *d_bvh = nullptr;
+    void *d_list_geom = nullptr, *d_list_ids = nullptr, *d_bvh = nullptr, *d_class_geom = nullptr, *d_class_ids = nullptr;
     bool use_bvh = false;
     int n_objects = 0;
     // render
@@ -616,10 +626,11 @@ struct ptx_context {
 };
 
 static void free_scene(ptx_context *c) {
-    for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels, c->d_list_geom, c->d_list_ids, c->d_bvh})
+    for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels, c->d_list_geom, c->d_list_ids, c->d_bvh, c->d_class_geom,
+                    c->d_class_ids})
         (void)hipFree(q);
     c->d_geom = c->d_mat = c->d_lights = c->d_images = c->d_texels = nullptr;
-    c->d_list_geom = c->d_list_ids = c->d_bvh = nullptr;
+    c->d_list_geom = c->d_list_ids = c->d_bvh = c->d_class_geom = c->d_class_ids = nullptr;
     c->have_scene = false;
 }
 static void free_render(ptx_context *c) {
@@ -824,10 +835,12 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         // half that size, which every shadow ray heads for.
         std::vector<char> direct(n, 0);
         int n_direct = 0;
+        double direct_factor = 16.0;
+        if (const char *e = getenv("PTX_DIRECT_FACTOR")) direct_factor = std::max(8.0, atof(e));  // for measurements
         for (int q = 0; q < n && n_direct < MAX_DIRECT; q++) {
             int k = order[q];
             if (!std::isfinite(extent[k])) continue;
-            const double factor = s->objects[k].is_light ? 8.0 : 16.0;
+            const double factor = s->objects[k].is_light ? 8.0 : direct_factor;
             if (!(extent[k] > 8.0 * median)) break;
             if (!(extent[k] > factor * median)) continue;
             direct[k] = 1;
@@ -840,6 +853,28 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     }
     std::vector<DevGeom> list_geom(list_ids.size() ? list_ids.size() : 1);
     for (size_t q = 0; q < list_ids.size(); q++) list_geom[q] = geom[list_ids[q]];
+    // the same list grouped by intersection routine, for the kernel that sets its queries up group by group
+    std::vector<DevGeom> class_geom(list_geom.size());
+    std::vector<int32_t> class_ids(list_ids.size() ? list_ids.size() : 1);
+    int32_t class_end[LC_N];
+    {
+        size_t w = 0;
+        for (int cls = 0; cls < LC_N; cls++) {
+            for (size_t q = 0; q < list_ids.size(); q++) {
+                const DevGeom &g = list_geom[q];
+                const int of = g.fast ? LC_FAST_SPHERE
+                               : g.type == PTX_SPHERE ? LC_SPHERE
+                               : g.type == PTX_PLANE ? LC_PLANE
+                               : g.type == PTX_TRIANGLE ? LC_TRIANGLE
+                               : g.type == PTX_CYL ? LC_CYL : LC_BOX;
+                if (of != cls) continue;
+                class_geom[w] = g;
+                class_ids[w] = list_ids[q];
+                w++;
+            }
+            class_end[cls] = (int32_t)w;
+        }
+    }
     PtxBvhNode *d_bvh = nullptr;
     int n_bvh_nodes = 0;
     // One node array per octant of ray directions (512 bytes per primitive in all; +56 % on the 8000-cube sponge and
@@ -867,6 +902,10 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     HIPCHK(hipMemcpy(c->d_list_geom, list_geom.data(), list_geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
     if (!list_ids.empty())
         HIPCHK(hipMemcpy(c->d_list_ids, list_ids.data(), list_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_class_geom, class_geom.size() * sizeof(DevGeom)));
+    HIPCHK(hipMalloc(&c->d_class_ids, class_ids.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(c->d_class_geom, class_geom.data(), class_geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_class_ids, class_ids.data(), class_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->d_geom, geom.size() * sizeof(DevGeom)));
     HIPCHK(hipMalloc(&c->d_mat, mat.size() * sizeof(DevMat)));
     HIPCHK(hipMalloc(&c->d_lights, lights.size() * sizeof(DevLight)));
@@ -887,6 +926,9 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     d.texels = (const uint8_t *)c->d_texels;
     d.list_geom = (const DevGeom *)c->d_list_geom;
     d.list_ids = (const int32_t *)c->d_list_ids;
+    d.class_geom = (const DevGeom *)c->d_class_geom;
+    d.class_ids = (const int32_t *)c->d_class_ids;
+    for (int cls = 0; cls < LC_N; cls++) d.class_end[cls] = class_end[cls];
     d.bvh = (const PtxBvhNode *)c->d_bvh;
     d.n_list = (int32_t)list_ids.size();
     d.n_bvh_nodes = n_bvh_nodes;
@@ -1011,7 +1053,7 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     const int round_max = (int)std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (buf_bytes / bytes_per_pass) & ~(size_t)3);
     if (round_max < 4) return fail(PTX_EINVAL, "sample buffer too small for four passes of this image");
     const bool pinhole = c->rp.aperture == 0;
-    const long slots = (long)c->n_cus * 4 * ((c->use_bvh || !pinhole) ? 3 : 4);  // waves the GPU holds at once
+    const long slots = (long)c->n_cus * 4 * (c->use_bvh ? PTX_BVH_WAVES : (!pinhole ? 3 : 4));  // waves the GPU holds at once
     // waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and
     // short enough runs that a slow tile does not hold the end of the launch (measured best between 16 and 32)
     long fill = 16;
@@ -1021,11 +1063,12 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     // and BubbleTea: leave the walk when at most exit_lanes lanes are still in it, test leaves leaf_batch at a time.
     bool sliced = true;
     if (const char *e = getenv("PTX_BVH_KERNEL")) sliced = strcmp(e, "whole") != 0;
-    int exit_lanes = 8, leaf_batch = 4, shade_min = 40, burst = 8;
+    int exit_lanes = 8, leaf_batch = 4, shade_min = 40, burst = 8, small_run = 8;
     if (const char *e = getenv("PTX_WALK_EXIT_LANES")) exit_lanes = std::max(0, std::min(63, atoi(e)));
     if (const char *e = getenv("PTX_WALK_LEAF_BATCH")) leaf_batch = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("PTX_WALK_SHADE_MIN")) shade_min = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("PTX_WALK_BURST")) burst = std::max(1, atoi(e));
+    if (const char *e = getenv("PTX_WALK_SMALL_RUN")) small_run = std::max(1, std::min(64, atoi(e)));
     c->n_trace_launches = 0;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int ka = k0; ka < k0 + nk; ka += round_max) {
@@ -1055,11 +1098,11 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
                 if (pinhole)
                     hipLaunchKernelGGL((k_trace_samples_bvh<F, true>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                        sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst);
+                                       exit_lanes, leaf_batch, shade_min, burst, small_run);
                 else
                     hipLaunchKernelGGL((k_trace_samples_bvh<F, false>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                        sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst);
+                                       exit_lanes, leaf_batch, shade_min, burst, small_run);
             } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                    sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);

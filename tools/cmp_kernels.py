@@ -1,11 +1,14 @@
 """Times the render kernels for hierarchy scenes against each other and checks that their images are equal.
-usage: cmp_kernels.py size spp [whole | sliced[:exit_lanes,leaf_batch,shade_min,burst]] ..."""
+usage: cmp_kernels.py size spp [whole | sliced[:exit_lanes,leaf_batch,shade_min,burst,small_run]] ..."""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import pathtracer_amd as pt
 from pathtracer_amd.scene import Scene
+if os.environ.get("PTX_LIB"):  # an alternative build of the library, for A/B measurements
+    from pathtracer_amd import device
+    device._LIB = device.load_library(os.environ["PTX_LIB"])
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 variants = sys.argv[3:] or ["whole", "sliced"]
@@ -16,7 +19,7 @@ for name, depth, ap in (("scifi", 12, 0.05), ("bubbletea", 12, 0.15)):
     for v in variants:
         kern, _, rest = v.partition(":")
         os.environ["PTX_BVH_KERNEL"] = kern
-        for var, val in zip(("PTX_WALK_EXIT_LANES", "PTX_WALK_LEAF_BATCH", "PTX_WALK_SHADE_MIN", "PTX_WALK_BURST"), rest.split(",") if rest else ()):
+        for var, val in zip(("PTX_WALK_EXIT_LANES", "PTX_WALK_LEAF_BATCH", "PTX_WALK_SHADE_MIN", "PTX_WALK_BURST", "PTX_WALK_SMALL_RUN"), rest.split(",") if rest else ()):
             os.environ[var] = val
         prm = pt.make_params(size, depth, 7, ap, seed=3)
         dev.render_begin(prm); dev.render_passes(0, 4); dev.sync()  # warm
