@@ -101,6 +101,19 @@ typedef struct ptx_scene_desc {
 
 /* Build flags of the reference Makefile (:6-16). */
 enum { PTX_USE_IS = 1, PTX_USE_ES = 2, PTX_USE_RR = 4 };
+/* Not in the reference, never the default: an estimator without the reference's known defects, for users who want
+ * the picture rather than parity.  With this flag
+ *  - the weight of the explicit light sample is clamped to [0, 1] (the reference clamps at 1 only, PathTracer.c:437,
+ *    so a light seen from behind subtracts light);
+ *  - a light met by a path counts unless the previous bounce already sampled the lights explicitly: the flag that
+ *    says so (CEL) is set after every diffuse bounce with explicit sampling, whether or not the shadow ray reached
+ *    the light, and cleared by mirror and refraction bounces (the reference sets it only when the light was
+ *    reached and lets it leak through the bounces that follow, PathTracer.c:431-445);
+ *  - the primary ray goes through a uniformly random point of its pixel, not the centre (two more random numbers
+ *    per path, drawn first);
+ *  - the accumulator is linear: rgb += colour, wght += 1 (the reference's is rgb += colour * 2^(-ln wght),
+ *    wght += R + G + B, PathTracer.c:646-652); the mean image is rgb / (wght - 1). */
+enum { PTX_CLEAN = 8 };
 
 /* Which stream of uniform numbers stands in for the reference's drand48().
  * PTX_RNG_COUNTER: stateless, u = mix(seed, pixel, sample, draw index); the
@@ -113,7 +126,7 @@ enum { PTX_RNG_COUNTER = 0, PTX_RNG_LCG48 = 1 };
 typedef struct ptx_render_params {
     int32_t sx;          /* image is sx by sx (PathTracer.c:521) */
     int32_t max_depth;   /* MAX_DEPTH (PathTracer.c:522) */
-    int32_t flags;       /* PTX_USE_IS | PTX_USE_ES | PTX_USE_RR */
+    int32_t flags;       /* PTX_USE_IS | PTX_USE_ES | PTX_USE_RR [| PTX_CLEAN] */
     int32_t rng_mode;    /* PTX_RNG_* */
     double aperture;     /* PathTracer.c:525-529 */
     uint64_t seed;

@@ -682,10 +682,16 @@ static void refract_ray(path_t *ps, const pt *p, pt *normal, const ptx_object *o
 
 /* Primary ray: PathTracer.c:625-641 with sampleLensPoint (:142-158),
  * focusRay (:160-195) and initRay (utils_path.h:211-230). */
-static void primary_ray(const ptx_camera *cam, int sx, int i, int j, double aperture, const pt *fp, rng_t *rng, path_t *ps) {
+/* jitter: PTX_CLEAN's random point of the pixel instead of its centre (not in the reference) */
+static void primary_ray_j(const ptx_camera *cam, int sx, int i, int j, double aperture, const pt *fp, rng_t *rng, path_t *ps, int jitter) {
     double du = cam->wsize / (sx - 1);
     double dv = -cam->wsize / (sx - 1);
     pt pc = {cam->wl + (i * du), cam->wt + (j * dv), cam->f, 1};
+    if (jitter) {
+        double ju = rnd(rng), jv = rnd(rng);
+        pc.x = cam->wl + ((i + (ju - 0.5)) * du);
+        pc.y = cam->wt + ((j + (jv - 0.5)) * dv);
+    }
     /* sampleLensPoint */
     double r = aperture * sqrt(rnd(rng));
     double theta = rnd(rng) * 2 * PI;
@@ -721,6 +727,9 @@ static void primary_ray(const ptx_camera *cam, int sx, int i, int j, double aper
     COL(ps, 0) = COL(ps, 1) = COL(ps, 2) = 1.0;
     INT(ps, 0) = INT(ps, 1) = INT(ps, 2) = 0;
     ps->mem[6] = 0; ps->mem[7] = 0; ps->mem[8] = 1; ps->mem[9] = 1; /* srcN */
+}
+static void primary_ray(const ptx_camera *cam, int sx, int i, int j, double aperture, const pt *fp, rng_t *rng, path_t *ps) {
+    primary_ray_j(cam, sx, i, j, aperture, fp, rng, ps, 0);
 }
 
 /* Light point samplers: planeSample/planeCoordinates (utils_path.c:1189,
@@ -854,14 +863,17 @@ static void path_trace(const orc_scene *sc, path_t *ps, int max_depth, int flags
                     double d2 = (rx - p.x) * (rx - p.x) + (ry - p.y) * (ry - p.y) + (rz - p.z) * (rz - p.z);
                     double weight2 = dot(&n, &ed) * -dot(&en, &ed);
                     double weight = rmin(1, (ho->surfaceArea * weight2) / d2);
+                    if ((flags & PTX_CLEAN) && weight < 0) weight = 0;
                     INT(ps, 0) += COL(ps, 0) * R * ho->col[0] * weight / (1 - RR_prob);
                     INT(ps, 1) += COL(ps, 1) * G * ho->col[1] * weight / (1 - RR_prob);
                     INT(ps, 2) += COL(ps, 2) * B * ho->col[2] * weight / (1 - RR_prob);
                 } else {
                     CEL = 0;
                 }
+                if (flags & PTX_CLEAN) CEL = 1;
             }
         } else if (dice <= (diffusivity + reflectivity)) {
+            if (flags & PTX_CLEAN) CEL = 0;
             COL(ps, 0) *= R / (1 - RR_prob);
             COL(ps, 1) *= G / (1 - RR_prob);
             COL(ps, 2) *= B / (1 - RR_prob);
@@ -872,6 +884,7 @@ static void path_trace(const orc_scene *sc, path_t *ps, int max_depth, int flags
                 ps->d.z += obj->refl_sig * random_normal(rng);
             }
         } else if (dice <= (diffusivity + reflectivity + transparency)) {
+            if (flags & PTX_CLEAN) CEL = 0;
             COL(ps, 0) *= R / (1 - RR_prob);
             COL(ps, 1) *= G / (1 - RR_prob);
             COL(ps, 2) *= B / (1 - RR_prob);
@@ -989,10 +1002,17 @@ void orc_render(const orc_scene *s, const ptx_render_params *prm, int k0, int nk
                     rng.script = NULL;
                     path_t ps;
                     double col[3];
-                    primary_ray(cam, sx, i, j, prm->aperture, &fp, &rng, &ps);
+                    primary_ray_j(cam, sx, i, j, prm->aperture, &fp, &rng, &ps, prm->flags & PTX_CLEAN);
                     double wt = wght[i + j * sx];
                     path_trace(s, &ps, prm->max_depth, prm->flags, &rng, col, &st);
                     st.paths++;
+                    if (prm->flags & PTX_CLEAN) { /* linear accumulator */
+                        rgb[(i + j * sx) * 3 + 0] += col[0];
+                        rgb[(i + j * sx) * 3 + 1] += col[1];
+                        rgb[(i + j * sx) * 3 + 2] += col[2];
+                        wght[i + j * sx] = wt + 1;
+                        continue;
+                    }
                     rgb[(i + j * sx) * 3 + 0] += col[0] * pow(2, -log(wt));
                     rgb[(i + j * sx) * 3 + 1] += col[1] * pow(2, -log(wt));
                     rgb[(i + j * sx) * 3 + 2] += col[2] * pow(2, -log(wt));
@@ -1019,7 +1039,7 @@ void orc_trace_pixels(const orc_scene *s, const ptx_render_params *prm, const in
     for (int q = 0; q < n; q++) {
         rng_t rng = {0, ptx_path_key(prm->seed, (uint64_t)pix_j[q] * prm->sx + pix_i[q], (uint64_t)samp[q]), 0, NULL, NULL};
         path_t ps;
-        primary_ray(cam, prm->sx, pix_i[q], pix_j[q], prm->aperture, &fp, &rng, &ps);
+        primary_ray_j(cam, prm->sx, pix_i[q], pix_j[q], prm->aperture, &fp, &rng, &ps, prm->flags & PTX_CLEAN);
         path_trace(s, &ps, prm->max_depth, prm->flags, &rng, &out[3 * q], &st);
     }
 }

@@ -10,6 +10,7 @@ PTX_SCENE_MAGIC = 0x31435358545450
 
 PLANE, SPHERE, CYL, TRIANGLE, CUBE, ROOM = range(6)
 USE_IS, USE_ES, USE_RR = 1, 2, 4
+CLEAN = 8  # PTX_CLEAN of ptx_scene.h: not the reference's estimator
 RNG_COUNTER, RNG_LCG48 = 0, 1
 
 OBJECT_DTYPE = np.dtype(

@@ -31,5 +31,6 @@ static_assert(sizeof(PtxBvhNode) == 32, "PtxBvhNode layout");
 // octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, nearer child first).  On success *d_nodes_out points to
 // n_orders arrays of *n_nodes_out = 2n-1 nodes each, back to back in device memory (caller frees with hipFree);
 // links are relative to the start of their own array.
-int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, hipStream_t stream,
+// use_sah: topology by the surface-area heuristic, built on the host, instead of the Morton-code build on the GPU.
+int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
                   PtxBvhNode **d_nodes_out, int *n_nodes_out, std::string &err);

@@ -10,6 +10,8 @@
 //   4. k_refit      boxes bottom-up, the second thread to reach a node continues upward
 //   5. k_order      per inner node and per octant of ray directions: which child lies nearer
 //   6. k_emit       nodes written in depth-first order with a "skip" link each, once per octant
+// Steps 1-3 have an alternative on the host, build_sah: the same arrays from a top-down build by the surface-area
+// heuristic, slower to make (a second for a million triangles against 0.2 s) and cheaper to walk.
 // The emitted array is walked without a stack: a node that is hit is followed by the next array entry, a node
 // that is missed (or a leaf that has been tested) by its skip link.  A fixed order meets the primitives of a ray
 // that travels against it last, after every box along the ray; with one array per octant -- the child that is
@@ -20,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -198,6 +202,148 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
     out[pre] = node;
 }
 
+// Topology by the surface-area heuristic, on the host: the same arrays k_hierarchy fills (a permutation of the
+// primitives in which every inner node covers a run first..last, its two children, the parents), so that refit,
+// child order and emission are shared with the Morton build.  Top-down; every node is split where
+// area(left) * count(left) + area(right) * count(right) is smallest among the planes between 16 bins of the
+// centroids on each axis; a node whose centroids coincide is cut in the middle.  One primitive per leaf.
+struct SahTopology {
+    std::vector<int> ids, left, right, parent_inner, parent_leaf, first, last;
+};
+
+void build_sah(const double *boxes, int n, SahTopology &t) {
+    t.ids.resize(n);
+    for (int i = 0; i < n; i++) t.ids[i] = i;
+    const int n_inner = n > 1 ? n - 1 : 1;
+    t.left.assign(n_inner, 0);
+    t.right.assign(n_inner, 0);
+    t.parent_inner.assign(n_inner, -1);
+    t.first.assign(n_inner, 0);
+    t.last.assign(n_inner, 0);
+    t.parent_leaf.assign(n, -1);
+    if (n < 2) return;
+    std::vector<float> cen(3 * (size_t)n);
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) cen[3 * (size_t)i + a] = (float)(0.5 * (boxes[6 * (size_t)i + 2 * a] + boxes[6 * (size_t)i + 2 * a + 1]));
+    struct Job {
+        int lo, hi, node;
+    };
+    std::vector<Job> stack;
+    stack.push_back({0, n - 1, 0});
+    int next_inner = 1;
+    constexpr int K = 16;
+    struct Bin {
+        float b[6];
+        int count;
+    };
+    auto grow = [](float *b, const double *x) {
+        for (int a = 0; a < 3; a++) {
+            b[2 * a] = std::min(b[2 * a], (float)x[2 * a]);
+            b[2 * a + 1] = std::max(b[2 * a + 1], (float)x[2 * a + 1]);
+        }
+    };
+    auto merge = [](float *b, const float *x) {
+        for (int a = 0; a < 3; a++) {
+            b[2 * a] = std::min(b[2 * a], x[2 * a]);
+            b[2 * a + 1] = std::max(b[2 * a + 1], x[2 * a + 1]);
+        }
+    };
+    auto area = [](const float *b) {
+        const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    const float empty[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    while (!stack.empty()) {
+        const Job job = stack.back();
+        stack.pop_back();
+        const int lo = job.lo, hi = job.hi, m = hi - lo + 1;
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = lo; q <= hi; q++)
+            for (int a = 0; a < 3; a++) {
+                const float c = cen[3 * (size_t)t.ids[q] + a];
+                cmin[a] = std::min(cmin[a], c);
+                cmax[a] = std::max(cmax[a], c);
+            }
+        int mid = -1;
+        if (m > 2) {
+            Bin bins[3][K];
+            float scale[3];
+            for (int a = 0; a < 3; a++) {
+                scale[a] = cmax[a] > cmin[a] ? (float)K * (1.0f - 1e-6f) / (cmax[a] - cmin[a]) : 0.0f;
+                for (int k = 0; k < K; k++) {
+                    memcpy(bins[a][k].b, empty, sizeof(empty));
+                    bins[a][k].count = 0;
+                }
+            }
+            for (int q = lo; q <= hi; q++) {
+                const int id = t.ids[q];
+                for (int a = 0; a < 3; a++) {
+                    if (scale[a] == 0.0f) continue;
+                    Bin &bn = bins[a][(int)((cen[3 * (size_t)id + a] - cmin[a]) * scale[a])];
+                    grow(bn.b, boxes + 6 * (size_t)id);
+                    bn.count++;
+                }
+            }
+            float best = INFINITY;
+            int best_axis = -1, best_k = 0;
+            for (int a = 0; a < 3; a++) {
+                if (scale[a] == 0.0f) continue;
+                float right_area[K];
+                float acc[6];
+                memcpy(acc, empty, sizeof(empty));
+                for (int k = K - 1; k >= 1; k--) {
+                    if (bins[a][k].count) merge(acc, bins[a][k].b);
+                    right_area[k] = area(acc);
+                }
+                memcpy(acc, empty, sizeof(empty));
+                int left_count = 0;
+                for (int k = 1; k < K; k++) {  // plane between bins k-1 and k
+                    if (bins[a][k - 1].count) merge(acc, bins[a][k - 1].b);
+                    left_count += bins[a][k - 1].count;
+                    if (left_count == 0 || left_count == m) continue;
+                    const float cost = area(acc) * (float)left_count + right_area[k] * (float)(m - left_count);
+                    if (cost < best) {
+                        best = cost;
+                        best_axis = a;
+                        best_k = k;
+                    }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                int *b = t.ids.data() + lo, *e = t.ids.data() + hi + 1;
+                int *split = std::partition(b, e, [&](int id) { return (int)((cen[3 * (size_t)id + a] - cmin[a]) * scale[a]) < best_k; });
+                mid = lo + (int)(split - b);
+                if (mid == lo || mid > hi) mid = -1;
+            }
+        }
+        if (mid < 0) {  // two primitives, or no plane separates the centroids: the middle along the longest axis
+            int a = 0;
+            for (int q = 1; q < 3; q++)
+                if (cmax[q] - cmin[q] > cmax[a] - cmin[a]) a = q;
+            mid = lo + m / 2;
+            std::nth_element(t.ids.begin() + lo, t.ids.begin() + mid, t.ids.begin() + hi + 1,
+                             [&](int x, int y) { return cen[3 * (size_t)x + a] < cen[3 * (size_t)y + a]; });
+        }
+        const int node = job.node;
+        t.first[node] = lo;
+        t.last[node] = hi;
+        for (int side = 0; side < 2; side++) {
+            const int clo = side ? mid : lo, chi = side ? hi : mid - 1;
+            int child;
+            if (clo == chi) {
+                child = ~clo;
+                t.parent_leaf[clo] = node;
+            } else {
+                child = next_inner++;
+                t.parent_inner[child] = node;
+                stack.push_back({clo, chi, child});
+            }
+            (side ? t.right : t.left)[node] = child;
+        }
+    }
+}
+
 #define BVHCHK(expr)                                                       \
     do {                                                                   \
         hipError_t e_ = (expr);                                            \
@@ -209,7 +355,7 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
 
 }  // namespace
 
-int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, hipStream_t stream,
+int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
                   PtxBvhNode **d_nodes_out, int *n_nodes_out, std::string &err) {
     *d_nodes_out = nullptr;
     *n_nodes_out = 0;
@@ -270,14 +416,29 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
     BVHCHK(hipMemsetAsync(d_arrived, 0, sizeof(int) * (size_t)n_inner, stream));
     BVHCHK(hipMemsetAsync(d_pleaf, 0xff, sizeof(int) * (size_t)n, stream));  // -1: a lone leaf has no parent
 
-    hipLaunchKernelGGL(k_morton, dim3(gb), dim3(256), 0, stream, d_boxes, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_codes, d_ids);
-    BVHCHK(hipGetLastError());
-    BVHCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_codes, d_codes2, d_ids, d_ids2, (size_t)n, 0, 64, stream));
-    BVHCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    BVHCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_codes, d_codes2, d_ids, d_ids2, (size_t)n, 0, 64, stream));
-    if (n > 1) {
-        hipLaunchKernelGGL(k_hierarchy, dim3(gb), dim3(256), 0, stream, d_codes2, n, d_left, d_right, d_pin, d_pleaf, d_first, d_last);
+    if (use_sah) {
+        SahTopology t;
+        build_sah(h_boxes, n, t);
+        BVHCHK(hipMemcpyAsync(d_ids2, t.ids.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_pleaf, t.parent_leaf.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_left, t.left.data(), sizeof(int) * (size_t)n_inner, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_right, t.right.data(), sizeof(int) * (size_t)n_inner, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_pin, t.parent_inner.data(), sizeof(int) * (size_t)n_inner, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_first, t.first.data(), sizeof(int) * (size_t)n_inner, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipMemcpyAsync(d_last, t.last.data(), sizeof(int) * (size_t)n_inner, hipMemcpyHostToDevice, stream));
+        BVHCHK(hipStreamSynchronize(stream));  // the vectors go out of scope
+    } else {
+        hipLaunchKernelGGL(k_morton, dim3(gb), dim3(256), 0, stream, d_boxes, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_codes, d_ids);
         BVHCHK(hipGetLastError());
+        BVHCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_codes, d_codes2, d_ids, d_ids2, (size_t)n, 0, 64, stream));
+        BVHCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+        BVHCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_codes, d_codes2, d_ids, d_ids2, (size_t)n, 0, 64, stream));
+        if (n > 1) {
+            hipLaunchKernelGGL(k_hierarchy, dim3(gb), dim3(256), 0, stream, d_codes2, n, d_left, d_right, d_pin, d_pleaf, d_first, d_last);
+            BVHCHK(hipGetLastError());
+        }
+    }
+    if (n > 1) {
         hipLaunchKernelGGL(k_refit, dim3(gb), dim3(256), 0, stream, d_boxes, d_ids2, n, d_left, d_right, d_pin, d_pleaf, d_inner_box,
                            d_arrived);
         BVHCHK(hipGetLastError());

@@ -187,6 +187,7 @@ struct DevRender {
     double aperture;
     uint64_t seed;
     double du, dv;
+    int32_t clean, pad;  // PTX_CLEAN asked for (ptx_scene.h): not the reference's behaviour
 };
 
 // ------------------------------------------------------------------ RNG
@@ -867,6 +868,11 @@ __device__ inline void primary_ray(const DevScene &sc, const DevRender &rp, cons
     ps.rng.ctr = ptx_path_key(rp.seed, (uint64_t)j * (uint64_t)rp.sx + (uint64_t)i, (uint64_t)k);
     const DevCamera &cam = sc.cam;
     V3 pc = mk(cam.wl + (i * rp.du), cam.wt + (j * rp.dv), cam.f);
+    if (rp.clean) {  // PTX_CLEAN: a random point of the pixel, not its centre
+        const double ju = ps.rng.next(), jv = ps.rng.next();
+        pc.x = cam.wl + ((i + (ju - 0.5)) * rp.du);
+        pc.y = cam.wt + ((j + (jv - 0.5)) * rp.dv);
+    }
     V3 pl = pc;
     if (rp.aperture != 0) {
         double r = rp.aperture * sqrt(ps.rng.next());
@@ -929,9 +935,12 @@ __device__ __forceinline__ V3 light_sample(const DevLight &ls, Rng &rng) {
 // that has used up its depth ends without another trip through the loop.
 // With DEFER_GLOSSY the three normal deviates of a glossy mirror bounce (:460-464) are not drawn here: the
 // lane reports its refl_sig in `glossy` (0 otherwise) and the caller adds them with glossy_service().
-template <int FLAGS, bool USE_BVH, bool DEFER_GLOSSY, bool COUNT = false>
+// ALLOW_CLEAN: the kernel honours rp.clean (PTX_CLEAN); the kernel specialised for a zero aperture is never asked
+// to, because a jittered primary ray differs from sample to sample like one through a lens.
+template <int FLAGS, bool USE_BVH, bool DEFER_GLOSSY, bool COUNT = false, bool ALLOW_CLEAN = true>
 __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const LaneStore &ls, Path &ps, Counters &cnt,
                               double &glossy, WalkCount *wc = nullptr) {
+    const bool clean = ALLOW_CLEAN && rp.clean != 0;
     glossy = 0;
     ps.d = norm3(ps.d);
     cnt.closest++;
@@ -1006,15 +1015,17 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                     double weight2 = dot3(n, ed) * -dot3(ln, ed);
                     double wgt = (lm.surfaceArea * weight2) * fast_rcp(d2);
                     wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
+                    if (clean && wgt < 0) wgt = 0;
                     wgt *= inv_keep;
                     ps.I = mk(ps.I.x + ps.col.x * R * lm.col[0] * wgt, ps.I.y + ps.col.y * G * lm.col[1] * wgt,
                               ps.I.z + ps.col.z * B * lm.col[2] * wgt);
                     lit = 1;
                 }
             }
-            ps.cel = lit;
+            ps.cel = clean ? 1 : lit;
         }
     } else if (dice <= diffusivity + reflectivity) {
+        if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         n = norm3(n);
         ps.d = reflect_dir(ps.d, n);
@@ -1030,6 +1041,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             }
         }
     } else if (dice <= diffusivity + reflectivity + transparency) {
+        if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
         next_os = -1;
@@ -1138,6 +1150,7 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
             result = SH_SHADOW;
         }
     } else if (dice <= diffusivity + reflectivity) {
+        if (rp.clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         n = norm3(n);
         ps.d = reflect_dir(ps.d, n);
@@ -1145,6 +1158,7 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
         const double sig = mt.refl_sig;
         if (sig > 0) glossy = sig;
     } else if (dice <= diffusivity + reflectivity + transparency) {
+        if (rp.clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
         next_os = -1;
@@ -1161,7 +1175,7 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
 }
 
 // sh: result of the shadow query from ps.p0 along pend.ed (os = ps.os).  Reference PathTracer.c:428-445.
-__device__ inline void apply_shadow(const DevScene &sc, Path &ps, const Hit &sh, const ShadowPending &pend) {
+__device__ inline void apply_shadow(const DevScene &sc, const DevRender &rp, Path &ps, const Hit &sh, const ShadowPending &pend) {
     int lit = 0;
     if (sh.obj >= 0) {
         const DevMat &lm = sc.mat[sh.obj];
@@ -1172,12 +1186,13 @@ __device__ inline void apply_shadow(const DevScene &sc, Path &ps, const Hit &sh,
             double weight2 = pend.n_ed * -dot3(ln, pend.ed);
             double wgt = (lm.surfaceArea * weight2) * pend.rcp_d2;
             wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
+            if (rp.clean && wgt < 0) wgt = 0;
             wgt *= pend.inv_keep;
             ps.I = mk(ps.I.x + pend.cr * lm.col[0] * wgt, ps.I.y + pend.cg * lm.col[1] * wgt, ps.I.z + pend.cb * lm.col[2] * wgt);
             lit = 1;
         }
     }
-    ps.cel = lit;
+    ps.cel = rp.clean ? 1 : lit;
 }
 
 // ------------------------------------------------ a closest-hit query carried in slices

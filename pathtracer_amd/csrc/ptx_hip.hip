@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
         if (__ballot(alive) == 0ULL) break;
         double glossy = 0;
 #ifdef PTX_PHASE_TIMERS
-        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true, true>(sc, rp, ls, ps, cnt, glossy, &wc_dbg);
+        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true, true, !PINHOLE>(sc, rp, ls, ps, cnt, glossy, &wc_dbg);
         iters_dbg++;
 #else
-        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true>(sc, rp, ls, ps, cnt, glossy);
+        if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true, false, !PINHOLE>(sc, rp, ls, ps, cnt, glossy);
 #endif
         glossy_service(ps, glossy, lane);
         if (alive && ended) {
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
             if (n_shadow > 0 && (n_shadow >= small_run || shade_now || n_busy == 0)) {
                 DBG_BEGIN();
                 if (ready_shadow) {
-                    apply_shadow(sc, ps, q.h, pend);
+                    apply_shadow(sc, rp, ps, q.h, pend);
                     ended = over;
                     mode = M_CLOSEST;
                     fresh = true;
@@ -450,13 +450,23 @@ __device__ __forceinline__ void fold_sample(double &ar, double &ag, double &ab, 
 
 // The accumulation for n_samples samples of every pixel, in sample order; one lane per pixel, four samples (one
 // 128-byte line of the lane's own stream) per trip.
+// linear: PTX_CLEAN's accumulator instead of the reference's, rgb += colour and wght += 1.
 __global__ void __launch_bounds__(256) k_fold_samples(const double *__restrict__ samples, size_t n_pix, size_t stride,
-                                                       int n_samples, double *__restrict__ rgb, double *__restrict__ wght) {
+                                                       int n_samples, double *__restrict__ rgb, double *__restrict__ wght, int linear) {
     const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= n_pix) return;
     double ar = rgb[pix * 3 + 0], ag = rgb[pix * 3 + 1], ab = rgb[pix * 3 + 2], wt = wght[pix];
     const double4 *in = (const double4 *)(samples + pix * stride * PTX_SAMPLE_DOUBLES);
     int q = 0;
+    if (linear) {
+        for (; q < n_samples; q++) {
+            const double4 s0 = in[q];
+            ar += s0.x;
+            ag += s0.y;
+            ab += s0.z;
+        }
+        wt += (double)n_samples;
+    }
     for (; q + 4 <= n_samples; q += 4) {
         const double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
         fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
@@ -892,7 +902,10 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
             const DevGeom &g = geom[bvh_ids[q]];
             leaves[q] = bvh_ids[q] | (g.fast ? PTX_LEAF_FAST : 0) | (g.type << PTX_LEAF_TYPE_SHIFT);
         }
-        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
+        // Topology: surface-area heuristic on the host up to 4 M primitives (PTX_BVH_BUILD=lbvh or sah overrides)
+        bool use_sah = leaves.size() <= (4u << 20);
+        if (const char *e = getenv("PTX_BVH_BUILD")) use_sah = strcmp(e, "lbvh") != 0;
+        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, use_sah, c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
             return fail(PTX_EDEVICE, "ptx_scene_upload: hierarchy build failed: " + err);
     }
     c->d_bvh = d_bvh;
@@ -953,7 +966,7 @@ static int fill_render(ptx_context *c, const ptx_render_params *p) {
     if (!c->have_scene) return fail(PTX_ESTATE, "no scene uploaded");
     if (p->sx < 2) return fail(PTX_EINVAL, "image size must be at least 2");
     if (p->rng_mode != PTX_RNG_COUNTER) return fail(PTX_EINVAL, "only PTX_RNG_COUNTER runs on the GPU");
-    if (p->flags & ~7) return fail(PTX_EINVAL, "unknown flag bits");
+    if (p->flags & ~(7 | PTX_CLEAN)) return fail(PTX_EINVAL, "unknown flag bits");
     int n_ranks = p->n_ranks <= 1 ? 1 : p->n_ranks;
     if (n_ranks > 1 && (p->rank < 0 || p->rank >= n_ranks || p->band_rows <= 0))
         return fail(PTX_EINVAL, "bad rank / n_ranks / band_rows");
@@ -964,6 +977,8 @@ static int fill_render(ptx_context *c, const ptx_render_params *p) {
     r.rank = n_ranks > 1 ? p->rank : 0; r.n_ranks = n_ranks; r.band_rows = n_ranks > 1 ? p->band_rows : p->sx;
     r.rows_owned = ptx_rows_owned(p->sx, r.rank, n_ranks, r.band_rows);
     r.aperture = p->aperture; r.seed = p->seed;
+    r.clean = (p->flags & PTX_CLEAN) ? 1 : 0;
+    r.pad = 0;
     r.du = c->sc.cam.wsize / (p->sx - 1);   // reference PathTracer.c:583-584
     r.dv = -c->sc.cam.wsize / (p->sx - 1);
     return PTX_OK;
@@ -1052,7 +1067,7 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     // multiple of four records
     const int round_max = (int)std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (buf_bytes / bytes_per_pass) & ~(size_t)3);
     if (round_max < 4) return fail(PTX_EINVAL, "sample buffer too small for four passes of this image");
-    const bool pinhole = c->rp.aperture == 0;
+    const bool pinhole = c->rp.aperture == 0 && !c->rp.clean;  // every sample of a pixel starts along the same direction
     const long slots = (long)c->n_cus * 4 * (c->use_bvh ? PTX_BVH_WAVES : (!pinhole ? 3 : 4));  // waves the GPU holds at once
     // waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and
     // short enough runs that a slow tile does not hold the end of the launch (measured best between 16 and 32)
@@ -1116,7 +1131,7 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
             c->n_trace_launches++;
         }
         hipLaunchKernelGGL(k_fold_samples, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, c->stream, buf, n_pix, (size_t)round_max, nka,
-                           c->d_rgb, c->d_wght);
+                           c->d_rgb, c->d_wght, c->rp.clean);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));

@@ -138,6 +138,7 @@ int main(int argc, char *argv[]) {
     prm.sx = sx;
     prm.max_depth = max_depth;
     prm.flags = flags;
+    if (getenv("PTX_CLEAN")) prm.flags |= PTX_CLEAN; /* not the reference's estimator: see ptx_scene.h */
     prm.rng_mode = PTX_RNG_COUNTER;
     prm.aperture = aperture;
     prm.seed = (uint64_t)time(NULL); /* the reference seeds drand48 from the clock too (PathTracer.c:560) */

@@ -140,3 +140,24 @@ def test_known_answers(oracles, golden_dir):
         for k in range(len(z["light_script"])):
             lib.orc_kat_light_sample(h, int(oi), _p(z["light_script"][k].copy()), _p(out))
             assert np.allclose(out, z["light_out"][li, k], rtol=0, atol=tol)
+
+
+def test_clean_mode_of_the_oracle(oracles):
+    """PTX_CLEAN (the estimator without the reference's defects, behind a flag): the accumulator is the plain sum of
+    the paths' colours, the weight counts samples, no path is negative, and the flag changes nothing unless set."""
+    import pathtracer_amd as pt
+    orc = oracles["cornell"]
+    sx, spp = 24, 6
+    prm = pt.make_params(sx, 6, 7 | pt.abi.CLEAN, 0.0, seed=4)
+    rgb, w, st = orc.render(prm, 0, spp)
+    assert np.array_equal(w, np.full(sx * sx, 1.0 + spp))
+    jj, ii = np.meshgrid(np.arange(sx), np.arange(sx), indexing="ij")
+    total = np.zeros((sx * sx, 3))
+    for k in range(spp):
+        total += orc.trace_pixels(prm, ii.ravel(), jj.ravel(), np.full(sx * sx, k)).reshape(-1, 3)
+    assert np.allclose(rgb.reshape(-1, 3), total, rtol=1e-13, atol=0)
+    assert rgb.min() >= 0
+    # jittered primary rays: two samples of a pixel on a wall's edge see different things more often than centred ones
+    plain = pt.make_params(sx, 6, 7, 0.0, seed=4)
+    assert not np.array_equal(orc.render(plain, 0, 1)[0], orc.render(prm, 0, 1)[0])
+
