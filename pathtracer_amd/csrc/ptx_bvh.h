@@ -14,7 +14,9 @@
 // the box, decides about a hit.  32 bytes a node: two 16-byte loads per step, and the eight
 // arrays of a scene of 8000 primitives (4 MB) stay within one L2.
 struct PtxBvhNode {
-    float box[6];  // xl xu yl yu zl zu, world space
+    float box[6];  // xl xu yl yu zl zu, world space; in the array of an octant of ray directions (eight-array build) the two
+                   // bounds of an axis are stored in the order a ray of that octant reaches them: the upper one first
+                   // on an axis along which the octant's rays travel downward
     int32_t skip;  // index of the first node after this node's subtree
     int32_t obj;   // leaf: what the caller gave for the primitive (see PTX_LEAF_*); inner node: -1
 };
@@ -32,5 +34,6 @@ static_assert(sizeof(PtxBvhNode) == 32, "PtxBvhNode layout");
 // n_orders arrays of *n_nodes_out = 2n-1 nodes each, back to back in device memory (caller frees with hipFree);
 // links are relative to the start of their own array.
 // use_sah: topology by the surface-area heuristic, built on the host, instead of the Morton-code build on the GPU.
+// *coord_bound (if not null): no bound of any node exceeds it in magnitude.
 int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
-                  PtxBvhNode **d_nodes_out, int *n_nodes_out, std::string &err);
+                  PtxBvhNode **d_nodes_out, int *n_nodes_out, float *coord_bound, std::string &err);

@@ -178,7 +178,7 @@ __device__ inline float outward(double x, int upper, double margin) {
 }
 
 __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__ ids, const int *__restrict__ prim_ids, int n,
-                       int o, double margin, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
+                       int o, int near_first, double margin, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_inner,
                        const int *__restrict__ parent_leaf, const int *__restrict__ first, const int *__restrict__ last,
                        const unsigned char *__restrict__ order, const double *__restrict__ inner_box,
                        PtxBvhNode *__restrict__ out) {
@@ -199,6 +199,13 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
         node.obj = prim_ids[ids[i]];
         node.skip = pre + 1;
     }
+    if (near_first)  // the array of an octant: on an axis along which its rays travel downward the upper bound comes first
+        for (int a = 0; a < 3; a++)
+            if ((o >> a) & 1) {
+                const float lower = node.box[2 * a];
+                node.box[2 * a] = node.box[2 * a + 1];
+                node.box[2 * a + 1] = lower;
+            }
     out[pre] = node;
 }
 
@@ -356,7 +363,7 @@ void build_sah(const double *boxes, int n, SahTopology &t) {
 }  // namespace
 
 int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
-                  PtxBvhNode **d_nodes_out, int *n_nodes_out, std::string &err) {
+                  PtxBvhNode **d_nodes_out, int *n_nodes_out, float *coord_bound, std::string &err) {
     *d_nodes_out = nullptr;
     *n_nodes_out = 0;
     if (n <= 0) return 0;
@@ -448,13 +455,14 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
         BVHCHK(hipGetLastError());
     }
     for (int o = 0; o < n_orders; o++) {
-        hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, o, margin, d_left, d_right, d_pin, d_pleaf,
+        hipLaunchKernelGGL(k_emit, dim3(gb2), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, o, n_orders == 8 ? 1 : 0, margin, d_left, d_right, d_pin, d_pleaf,
                            d_first, d_last, d_order, d_inner_box, d_nodes + (size_t)o * (2 * n - 1));
         BVHCHK(hipGetLastError());
     }
     BVHCHK(hipStreamSynchronize(stream));
     *d_nodes_out = d_nodes;
     *n_nodes_out = 2 * n - 1;
+    if (coord_bound) *coord_bound = (float)((scale + margin) * (1.0 + 1e-6));
     d_nodes = nullptr;
     rc = 0;
 done:

@@ -179,6 +179,7 @@ struct DevScene {
     const DevGeom *class_geom;  // the always-tested primitives grouped by intersection routine (LC_*), ascending scene
     const int32_t *class_ids;   // index within a group, and their scene indices
     int32_t class_end[6];       // where each group ends in class_geom
+    float bvh_bound;            // no bound of any hierarchy node exceeds this in magnitude
 };
 
 struct DevRender {
@@ -1205,13 +1206,35 @@ __device__ inline void apply_shadow(const DevScene &sc, const DevRender &rp, Pat
 //   query_leaf()   the primitive test of the noted leaf
 // The query is over when node >= sc.n_bvh_nodes and leaf < 0.  The closest hit, ties included, does not depend on
 // the order of the tests, so the result has the bits closest_hit_all gives.
+// The box test of the walk is done in single precision, made safe by slack: with i = 1/d and o = p0/d rounded to
+// single precision, bound * i - o differs from the double-precision value closest_hit_all tests by at most
+// 2^-23 (|bound * i| + |o|), so the entry plane is tested with o + e and the exit plane with o - e,
+// e = 2^-21 (B |i| + |o|), B the largest magnitude of any bound (DevScene::bvh_bound), and the best hit's distance
+// is rounded upward.  The test then enters every node the double-precision test enters (and a few more, whose
+// primitives are tested in double precision like all others), at a third of the instructions.
 struct Query {
-    double ix, iy, iz, ox, oy, oz;  // slab test: t = bound * i - o
+    float ix, iy, iz;     // 1/d (a huge value of the octant's sign for a component that is zero)
+    float nx, ny, nz;     // o + e: subtracted on the plane a ray reaches first
+    float fx, fy, fz;     // o - e: subtracted on the plane it reaches second
+    float best;           // h.lambda rounded upward
     Hit h;
     int node;  // next node to visit, relative to the start of the octant's array
     int base;  // where that array starts in sc.bvh
     int leaf;  // >= 0: PtxBvhNode::obj of a leaf waiting for its primitive test
 };
+// 1/x in single precision for the walk: of the same sign as the octant bit computed from x < 0, finite, and huge
+// (2^100) for a component too small for its reciprocal (the double-precision walk uses 2^500 there; both put the
+// two planes hugely far on either side of a ray that runs between them and both on one side otherwise)
+__device__ __forceinline__ float rcp_for_slab32(double x) {
+    const double r = fabs(x) < 0x1p-100 ? (x < 0 ? -0x1p100 : 0x1p100) : fast_rcp(x);
+    return (float)r;
+}
+__device__ __forceinline__ void query_axis32(double p, float i, float bound, float &near_o, float &far_o) {
+    const double o = p * (double)i;
+    const double e = 0x1p-21 * ((double)bound * fabs((double)i) + fabs(o));
+    near_o = __double2float_ru(o + e);
+    far_o = __double2float_rd(o - e);
+}
 __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int os, Query &q) {
     q.h.lambda = INFINITY;
     q.h.obj = -1;
@@ -1250,12 +1273,13 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
         const double lam = isect_box(&cg[k].m[0], p0, d, part);
         take(ids[k], lam, part);
     }
-    q.ix = rcp_for_slab(d.x);
-    q.iy = rcp_for_slab(d.y);
-    q.iz = rcp_for_slab(d.z);
-    q.ox = p0.x * q.ix;
-    q.oy = p0.y * q.iy;
-    q.oz = p0.z * q.iz;
+    q.best = __double2float_ru(q.h.lambda);
+    q.ix = rcp_for_slab32(d.x);
+    q.iy = rcp_for_slab32(d.y);
+    q.iz = rcp_for_slab32(d.z);
+    query_axis32(p0.x, q.ix, sc.bvh_bound, q.nx, q.fx);
+    query_axis32(p0.y, q.iy, sc.bvh_bound, q.ny, q.fy);
+    query_axis32(p0.z, q.iz, sc.bvh_bound, q.nz, q.fz);
     const int octant = sc.bvh_per_octant ? ((d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2) : 0;
     q.base = octant * sc.n_bvh_nodes;
     q.node = 0;
@@ -1265,13 +1289,16 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
 __device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q) {
     const float4 *np = (const float4 *)(sc.bvh + (size_t)(uint32_t)(q.base + q.node));
     const float4 lo = np[0], hi = np[1];  // box[0..3]; box[4], box[5], skip, obj
-    double t0 = fma((double)lo.x, q.ix, -q.ox), t1 = fma((double)lo.y, q.ix, -q.ox);
-    double t2 = fma((double)lo.z, q.iy, -q.oy), t3 = fma((double)lo.w, q.iy, -q.oy);
-    double t4 = fma((double)hi.x, q.iz, -q.oz), t5 = fma((double)hi.y, q.iz, -q.oz);
-    double lmin = fmax(fmax(fmin(t0, t1), fmin(t2, t3)), fmin(t4, t5));
-    double lmax = fmin(fmin(fmax(t0, t1), fmax(t2, t3)), fmax(t4, t5));
+    float x0 = lo.x, x1 = lo.y, y0 = lo.z, y1 = lo.w, z0 = hi.x, z1 = hi.y;
+    if (!sc.bvh_per_octant) {  // one array for all directions: the plane reached first is the lower one if i >= 0
+        if (q.ix < 0) { x0 = lo.y; x1 = lo.x; }
+        if (q.iy < 0) { y0 = lo.w; y1 = lo.z; }
+        if (q.iz < 0) { z0 = hi.y; z1 = hi.x; }
+    }
+    const float lmin = fmaxf(fmaxf(fmaf(x0, q.ix, -q.nx), fmaf(y0, q.iy, -q.ny)), fmaf(z0, q.iz, -q.nz));
+    const float lmax = fminf(fminf(fmaf(x1, q.ix, -q.fx), fmaf(y1, q.iy, -q.fy)), fmaf(z1, q.iz, -q.fz));
     const int skip = __float_as_int(hi.z), obj = __float_as_int(hi.w);
-    const bool enter = !(lmin > lmax) && !(lmax < 0) && !(lmin > q.h.lambda);
+    const bool enter = !(lmin > lmax) && !(lmax < 0) && !(lmin > q.best);
     q.leaf = (enter && obj >= 0 && (obj & PTX_LEAF_INDEX) != os) ? obj : -1;
     q.node = enter ? q.node + 1 : skip;
 }
@@ -1284,6 +1311,7 @@ __device__ __forceinline__ void query_leaf(const DevScene &sc, V3 p0, V3 d, Quer
         q.h.lambda = lam;
         q.h.obj = id;
         q.h.part = part;
+        q.best = __double2float_ru(lam);
     }
     q.leaf = -1;
 }

@@ -887,6 +887,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     }
     PtxBvhNode *d_bvh = nullptr;
     int n_bvh_nodes = 0;
+    float bvh_bound = 0;
     // One node array per octant of ray directions (512 bytes per primitive in all; +56 % on the 8000-cube sponge and
     // +23 % on a million triangles over a single array), a single array beyond 16 M primitives.
     // PTX_BVH_ORDERS=1 or 8 overrides the choice (for measurements).
@@ -905,7 +906,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         // Topology: surface-area heuristic on the host up to 4 M primitives (PTX_BVH_BUILD=lbvh or sah overrides)
         bool use_sah = leaves.size() <= (4u << 20);
         if (const char *e = getenv("PTX_BVH_BUILD")) use_sah = strcmp(e, "lbvh") != 0;
-        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, use_sah, c->stream, &d_bvh, &n_bvh_nodes, err) != 0)
+        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, use_sah, c->stream, &d_bvh, &n_bvh_nodes, &bvh_bound, err) != 0)
             return fail(PTX_EDEVICE, "ptx_scene_upload: hierarchy build failed: " + err);
     }
     c->d_bvh = d_bvh;
@@ -946,6 +947,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     d.n_list = (int32_t)list_ids.size();
     d.n_bvh_nodes = n_bvh_nodes;
     d.bvh_per_octant = bvh_orders == 8;
+    d.bvh_bound = bvh_bound;
     d.n_objects = n; d.n_lights = s->n_lights; d.n_images = s->n_images; d.has_refraction = has_refr;
     const ptx_camera &cam = s->cam;
     for (int q = 0; q < 3; q++) { d.cam.e[q] = cam.e[q]; d.cam.w[q] = cam.w[q]; }

@@ -66,3 +66,19 @@ def test_row_band_helpers():
         assert sorted(int(x) for r in rows for x in r) == list(range(sx))
         for r in range(world):
             assert len(rows[r]) == abi.rows_owned(sx, r, world, band)
+
+
+def test_benchmark_kernel_stays_within_its_register_budget():
+    """k_trace_samples<7, false, true> (small scene, zero aperture, IS+ES+RR) is compiled for four waves per SIMD:
+    128 vector registers and at most 80 bytes of scratch per lane.  It gets there only with machine-level
+    loop-invariant code motion switched off (pathtracer_amd/Makefile); with the pass on, its sixty double-precision
+    literals land in 500 bytes of scratch per lane and the benchmark loses a quarter.  The code object says which."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(repo, "pathtracer_amd", "build", "ptx_hip.o")
+    if not os.path.exists(obj):
+        pytest.skip("object file not built here")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "kernel_regs.py"), "--check", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
