@@ -214,9 +214,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
 #define DBG_BEGIN() (dbg_t = clock64())
 #define DBG_END(slot_cyc, slot_n, slot_l, pred)                 \
     do {                                                        \
+        const int lanes_ = __popcll(__ballot(pred));            \
         dbg[slot_cyc] += (unsigned long long)(clock64() - dbg_t); \
-        dbg[slot_n] += 1;                                       \
-        dbg[slot_l] += __popcll(__ballot(pred));                \
+        dbg[slot_n] += lanes_ > 0;                              \
+        dbg[slot_l] += lanes_;                                  \
     } while (0)
 #else
 #define DBG_BEGIN() ((void)0)
