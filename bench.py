@@ -37,12 +37,16 @@ def recorded_hbm_traffic(rows, sx):
                 rec = json.load(f)
             if rec.get("kernel") != "k_trace_samples" or rec.get("workload", "bench") != "bench":
                 continue
-            best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path))
+            # FP64 operations executed per launch, as the counters saw them: (2 FMA + ADD + MUL wave-instructions) x the
+            # average number of active lanes per vector instruction
+            flop = rec.get("f64_flop_counted", 0) * rec.get("active_lanes_per_valu_inst", 0) / max(1, rec.get("launches_per_run", 1))
+            best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path), flop)
         except (OSError, ValueError, KeyError):
             continue
     if best is None:
-        return None, None
-    return best[0] * (rows * sx) / float(1024 * 1024), best[1]
+        return None, None, None
+    share = (rows * sx) / float(1024 * 1024)
+    return best[0] * share, best[1], best[2] * share
 
 
 def cpu_baseline(sx, depth, flags, seconds_target=15.0):
@@ -225,7 +229,8 @@ def run(args):
     achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
     rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
     same_workload = sx == 1024 and spp == 1000 and chunk == spp and depth == 6
-    traffic, traffic_src = recorded_hbm_traffic(rows, sx) if same_workload else (None, None)
+    traffic, traffic_src, counted_flop = recorded_hbm_traffic(rows, sx) if same_workload else (None, None, None)
+    executed_tflops = counted_flop / (ms_sum / max(1, n_launches) * 1e-3) / 1e12 if counted_flop and ms_sum > 0 else None
     out = {
         "metric": "paths/s (pixel-samples per second), Cornell box 1024^2 depth 6 IS+ES+RR",
         "value": paths_per_s,
@@ -256,6 +261,8 @@ def run(args):
             "unit": "TFLOP/s",
             "frac": achieved_tflops / PEAK_FP32_TFLOPS,
             "frac_of_fp64_vector_peak": achieved_tflops / PEAK_FP64_TFLOPS,
+            "executed_fp64_tflops": executed_tflops,
+            "executed_frac_of_fp64_vector_peak": None if executed_tflops is None else executed_tflops / PEAK_FP64_TFLOPS,
             "traffic": traffic,
             "traffic_source": None if traffic_src is None else f"recorded: profiles/{traffic_src} (same workload, counters of an earlier run)",
             "algorithmic_hbm_bytes_per_launch": 32 * paths_launches // max(1, n_launches),
@@ -264,8 +271,8 @@ def run(args):
             "flop_per_path_model": FLOP_PER_PATH,
             "note": "achieved = paths x a MODEL of 3.9 kFLOP per path (not a counter) / kernel time; peak = vector FP32 "
                     "(no MFMA: the work is not a dense contraction); the arithmetic runs in FP64, whose vector peak is "
-                    "78.6 TFLOP/s (frac_of_fp64_vector_peak); the FP64 operations the counters see are listed in "
-                    "profiles/*_pmc.json",
+                    "78.6 TFLOP/s (frac_of_fp64_vector_peak); executed_fp64_tflops = the FP64 operations the hardware "
+                    "counters recorded for one launch of this workload (traffic_source) / this run's kernel time",
         },
     }
     if rank == 0:

@@ -145,11 +145,20 @@ struct DevLight {
     double T[12];   // rows 0..2 of T
 };
 
+// Texels are the bytes of the image file, row by row as in the file (tiles_x = 0).  With PTX_TEXEL_LAYOUT=tiled at upload
+// the three-channel images of a scene with a hierarchy are stored in tiles of 8 x 4 texels, a tile to a 128-byte line
+// (96 bytes used), tiles row by row (tiles_x > 0): the four texels of a bilinear look-up are two rows apart in the
+// file's order (3 sx bytes, two cache lines for every look-up) and lie in one line for two look-ups in three in the
+// tiled one.  Measured, that saves L2 requests and no time, so the file's order is the default.
 struct DevImage {
-    int32_t sx, sy, channels, pad;
+    int32_t sx, sy, channels, tiles_x;
     double divisor;
     uint64_t offset;
 };
+// byte offset of channel 0 of texel (x, y) of a tiled image, relative to DevImage::offset
+__device__ __forceinline__ long tiled_texel(const DevImage &im, int x, int y) {
+    return ((long)(y >> 2) * im.tiles_x + (x >> 3)) * 128 + ((y & 3) * 8 + (x & 7)) * 3;
+}
 
 struct DevCamera {
     double e[3], w[3];
@@ -597,13 +606,23 @@ __device__ __forceinline__ double texel_value(double byte, double divisor, doubl
     const double q = byte * inv;
     return fma(fma(-q, divisor, byte), inv, q);
 }
+// texel (flat index idx of the file's order, clamped to the image buffer where the reference reads out of bounds)
+// TILES: the kernel may meet tiled images (the kernels for scenes with a hierarchy; ptx_scene_upload tiles for those only)
+template <bool TILES>
 __device__ __forceinline__ double texel_at(const DevScene &sc, const DevImage &im, double inv, long idx, long n) {
     idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
-    return texel_value((double)sc.texels[im.offset + idx], im.divisor, inv);
+    long at = idx;
+    if (TILES && im.tiles_x > 0) {  // tiled: from the flat index back to texel and channel
+        const long t = idx / 3;
+        const int ch = (int)(idx - 3 * t), y = (int)(t / im.sx), x = (int)(t - (long)y * im.sx);
+        at = tiled_texel(im, x, y) + ch;
+    }
+    return texel_value((double)sc.texels[im.offset + at], im.divisor, inv);
 }
 // texMap, reference utils_path.c:1322-1374 (flat index clamped to the image
 // buffer where the reference reads out of bounds).
-// WIDE: fetch the two texels of a row with one load where all four lie inside the image.  The kernels for
+// WIDE: the kernel is one for scenes with a hierarchy: images may be tiled, and the two texels of a row are fetched
+// with one load where all four lie inside the image.  The kernels for
 // hierarchy scenes, which spend much of their time waiting for memory, gain 3 % by it; in the kernels for small
 // scenes the extra code only costs registers (1.5 % on the Cornell box, which has no textures at all).
 template <bool WIDE>
@@ -616,17 +635,32 @@ __device__ __forceinline__ void tex_map(const DevScene &sc, int img, double a, d
     const double inv = fast_rcp(im.divisor);
     double out[3];
     if (WIDE && x1 >= 0 && y1 >= 0 && x2 < im.sx && y2 < im.sy) {
-        // all four texels inside the image: the two of a row are six adjacent bytes, fetched with one load (the
-        // texel buffer ends in eight spare bytes)
-        uint64_t row1, row2;
-        __builtin_memcpy(&row1, sc.texels + im.offset + 3L * ((long)y1 * im.sx + x1), 8);
-        __builtin_memcpy(&row2, sc.texels + im.offset + 3L * ((long)y2 * im.sx + x1), 8);
+        // all four texels inside the image; each arrives as the low three bytes of a word (the texel buffer ends in
+        // spare bytes).  File order: the two texels of a row are six adjacent bytes, one 8-byte load.  Tiled: a
+        // 4-byte load per texel (the second texel of a row may be the first of the next tile), the four mostly in
+        // one cache line.
+        const uint8_t *base = sc.texels + im.offset;
+        uint32_t t11, t21, t12, t22;
+        if (im.tiles_x > 0) {
+            __builtin_memcpy(&t11, base + tiled_texel(im, x1, y1), 4);
+            __builtin_memcpy(&t21, base + tiled_texel(im, x2, y1), 4);
+            __builtin_memcpy(&t12, base + tiled_texel(im, x1, y2), 4);
+            __builtin_memcpy(&t22, base + tiled_texel(im, x2, y2), 4);
+        } else {
+            uint64_t row1, row2;
+            __builtin_memcpy(&row1, base + 3L * ((long)y1 * im.sx + x1), 8);
+            __builtin_memcpy(&row2, base + 3L * ((long)y2 * im.sx + x1), 8);
+            t11 = (uint32_t)row1;
+            t21 = (uint32_t)(row1 >> 24);
+            t12 = (uint32_t)row2;
+            t22 = (uint32_t)(row2 >> 24);
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            double c11 = texel_value((double)(uint32_t)((row1 >> (8 * c)) & 255), im.divisor, inv);
-            double c21 = texel_value((double)(uint32_t)((row1 >> (8 * c + 24)) & 255), im.divisor, inv);
-            double c12 = texel_value((double)(uint32_t)((row2 >> (8 * c)) & 255), im.divisor, inv);
-            double c22 = texel_value((double)(uint32_t)((row2 >> (8 * c + 24)) & 255), im.divisor, inv);
+            double c11 = texel_value((double)((t11 >> (8 * c)) & 255u), im.divisor, inv);
+            double c21 = texel_value((double)((t21 >> (8 * c)) & 255u), im.divisor, inv);
+            double c12 = texel_value((double)((t12 >> (8 * c)) & 255u), im.divisor, inv);
+            double c22 = texel_value((double)((t22 >> (8 * c)) & 255u), im.divisor, inv);
             double avg1 = c11 * (x2 - x) + c21 * (x - x1);
             double avg2 = c12 * (x2 - x) + c22 * (x - x1);
             out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
@@ -634,10 +668,10 @@ __device__ __forceinline__ void tex_map(const DevScene &sc, int img, double a, d
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            double c11 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x1) + c, n);
-            double c12 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x1) + c, n);
-            double c21 = texel_at(sc, im, inv, 3L * ((long)y1 * im.sx + x2) + c, n);
-            double c22 = texel_at(sc, im, inv, 3L * ((long)y2 * im.sx + x2) + c, n);
+            double c11 = texel_at<WIDE>(sc, im, inv, 3L * ((long)y1 * im.sx + x1) + c, n);
+            double c12 = texel_at<WIDE>(sc, im, inv, 3L * ((long)y2 * im.sx + x1) + c, n);
+            double c21 = texel_at<WIDE>(sc, im, inv, 3L * ((long)y1 * im.sx + x2) + c, n);
+            double c22 = texel_at<WIDE>(sc, im, inv, 3L * ((long)y2 * im.sx + x2) + c, n);
             double avg1 = c11 * (x2 - x) + c21 * (x - x1);
             double avg2 = c12 * (x2 - x) + c22 * (x - x1);
             out[c] = avg1 * (y2 - y) + avg2 * (y - y1);
@@ -655,10 +689,10 @@ __device__ __forceinline__ double alpha_map(const DevScene &sc, int img, double 
     int x2 = x1 + 1, y2 = y1 + 1;
     long n = (long)im.sx * im.sy;
     const double inv = fast_rcp(im.divisor);
-    double a11 = texel_at(sc, im, inv, (long)y1 * im.sx + x1, n);
-    double a12 = texel_at(sc, im, inv, (long)y2 * im.sx + x1, n);
-    double a21 = texel_at(sc, im, inv, (long)y1 * im.sx + x2, n);
-    double a22 = texel_at(sc, im, inv, (long)y2 * im.sx + x2, n);
+    double a11 = texel_at<false>(sc, im, inv, (long)y1 * im.sx + x1, n);
+    double a12 = texel_at<false>(sc, im, inv, (long)y2 * im.sx + x1, n);
+    double a21 = texel_at<false>(sc, im, inv, (long)y1 * im.sx + x2, n);
+    double a22 = texel_at<false>(sc, im, inv, (long)y2 * im.sx + x2, n);
     double avg1 = a11 * (x2 - x) + a21 * (x - x1);
     double avg2 = a12 * (x2 - x) + a22 * (x - x1);
     return avg1 * (y2 - y) + avg2 * (y - y1);

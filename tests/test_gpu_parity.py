@@ -469,6 +469,23 @@ def test_sliced_queries_do_not_change_results(name, ap, gpu, monkeypatch):
             assert np.array_equal(rgb, got[0][0], equal_nan=True) and np.array_equal(w, got[0][1], equal_nan=True) and st == got[0][2]
 
 
+@pytest.mark.parametrize("name", ["scifi", "bubbletea"])
+def test_texel_layout_does_not_change_results(name, scenes, monkeypatch):
+    """PTX_TEXEL_LAYOUT=tiled stores three-channel images in 8 x 4 texel tiles, one to a cache line; the look-ups
+    fetch the same bytes, so first-hit texture coordinates aside nothing changes: images equal bit for bit."""
+    got = []
+    for layout in ("linear", "tiled"):
+        monkeypatch.setenv("PTX_TEXEL_LAYOUT", layout)
+        dev = pt.Device(0)
+        dev.scene_upload(scenes[name])
+        dev.render_begin(pt.make_params(56, 8, ALL, 0.05, seed=6))
+        dev.render_passes(0, 4)
+        got.append(dev.download() + (dev.stats(),))
+        dev.close()
+    assert np.array_equal(got[0][0], got[1][0], equal_nan=True) and np.array_equal(got[0][1], got[1][1], equal_nan=True)
+    assert got[0][2] == got[1][2]
+
+
 def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
     """A render_passes call traces its samples in as many rounds as the sample buffer needs and cuts each round
     into waves of whatever length fills the GPU; the accumulator is folded in sample order all the same, so the
