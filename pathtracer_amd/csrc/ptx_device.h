@@ -1255,6 +1255,9 @@ struct Query {
     int node;  // next node to visit, relative to the start of the octant's array
     int base;  // where that array starts in sc.bvh
     int leaf;  // >= 0: PtxBvhNode::obj of a leaf waiting for its primitive test
+#ifdef PTX_LDS_TOP
+    int oct;   // which octant's array (the experiment with the arrays' first entries in LDS)
+#endif
 };
 // 1/x in single precision for the walk: of the same sign as the octant bit computed from x < 0, finite, and huge
 // (2^100) for a component too small for its reciprocal (the double-precision walk uses 2^500 there; both put the
@@ -1318,11 +1321,28 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
     q.base = octant * sc.n_bvh_nodes;
     q.node = 0;
     q.leaf = -1;
+#ifdef PTX_LDS_TOP
+    q.oct = octant;
+#endif
 }
 // Free of branches, and the node fetched as two 16-byte words whatever the outcome of the box test.
-__device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q) {
-    const float4 *np = (const float4 *)(sc.bvh + (size_t)(uint32_t)(q.base + q.node));
-    const float4 lo = np[0], hi = np[1];  // box[0..3]; box[4], box[5], skip, obj
+// top, top_nodes: a copy in LDS of the first top_nodes entries of each octant's array (or null, 0): an experiment,
+// see k_trace_samples_bvh.
+#define PTX_LDS_TOP_MAX 12
+__device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q, const float4 *top = nullptr, int top_nodes = 0) {
+    float4 lo, hi;  // box[0..3]; box[4], box[5], skip, obj
+#ifdef PTX_LDS_TOP
+    if (q.node < top_nodes) {
+        const float4 *np = top + 2 * (q.oct * PTX_LDS_TOP_MAX + q.node);
+        lo = np[0];
+        hi = np[1];
+    } else
+#endif
+    {
+        const float4 *np = (const float4 *)(sc.bvh + (size_t)(uint32_t)(q.base + q.node));
+        lo = np[0];
+        hi = np[1];
+    }
     float x0 = lo.x, x1 = lo.y, y0 = lo.z, y1 = lo.w, z0 = hi.x, z1 = hi.y;
     if (!sc.bvh_per_octant) {  // one array for all directions: the plane reached first is the lower one if i >= 0
         if (q.ix < 0) { x0 = lo.y; x1 = lo.x; }

@@ -182,7 +182,7 @@ template <int FLAGS, bool PINHOLE>
 __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     k_trace_samples_bvh(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, int n_work, size_t stride,
                         double *__restrict__ samples, unsigned long long *__restrict__ stats, unsigned int *__restrict__ work_counter,
-                        int exit_lanes, int leaf_batch, int shade_min, int burst, int small_run) {
+                        int exit_lanes, int leaf_batch, int shade_min, int burst, int small_run, int lds_nodes) {
     enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
     __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
@@ -190,6 +190,23 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     const int lane = threadIdx.x & 63;
     const int tiles_x = (rp.sx + 7) >> 3;
     const int n_nodes = sc.n_bvh_nodes;
+#ifdef PTX_LDS_TOP
+    // Experiment (PTX_WALK_LDS_NODES=n, n <= 12, in a build with -DPTX_LDS_TOP): the first n entries of every octant's node
+    // array in LDS, a copy per wave.  The arrays are in depth-first order, so these are the root and the chain of nearer
+    // children below it: the first steps of every walk.
+    __shared__ float4 lds_top_[8 * PTX_LDS_TOP_MAX * 2];
+    if (lds_nodes > n_nodes) lds_nodes = n_nodes;
+    for (int t = lane; t < 8 * lds_nodes * 2; t += 64) {
+        const int oct = t / (2 * lds_nodes), rest = t - oct * 2 * lds_nodes;
+        const int src_oct = sc.bvh_per_octant ? oct : 0;
+        lds_top_[2 * oct * PTX_LDS_TOP_MAX + rest] = ((const float4 *)(sc.bvh + (size_t)src_oct * n_nodes))[rest];
+    }
+    __syncthreads();
+    const float4 *top = lds_top_;
+#else
+    const float4 *top = nullptr;
+    lds_nodes = 0;
+#endif
     // the lane's pixel and sample range (none yet: k == ke)
     int i = 0, j = 0, ks = 0, ke = 0, k = 0;
     size_t pix = 0;
@@ -388,11 +405,11 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
 #ifdef PTX_PHASE_TIMERS
             const bool dbg_walking = q.leaf < 0 && q.node < n_nodes;
             for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) {
-                query_step(sc, ps.os, q);
+                query_step(sc, ps.os, q, top, lds_nodes);
                 dbg[D_L_STEPS]++;
             }
 #else
-            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) query_step(sc, ps.os, q);
+            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) query_step(sc, ps.os, q, top, lds_nodes);
 #endif
             DBG_END(D_STEPS, D_N_BURST, D_L_BURST, dbg_walking);
             const bool paused = q.leaf >= 0;
@@ -1114,6 +1131,8 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     if (const char *e = getenv("PTX_WALK_SHADE_MIN")) shade_min = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("PTX_WALK_BURST")) burst = std::max(1, atoi(e));
     if (const char *e = getenv("PTX_WALK_SMALL_RUN")) small_run = std::max(1, std::min(64, atoi(e)));
+    int lds_nodes = 0;
+    if (const char *e = getenv("PTX_WALK_LDS_NODES")) lds_nodes = std::max(0, std::min(PTX_LDS_TOP_MAX, atoi(e)));
     c->n_trace_launches = 0;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int ka = k0; ka < k0 + nk; ka += round_max) {
@@ -1143,11 +1162,11 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
                 if (pinhole)
                     hipLaunchKernelGGL((k_trace_samples_bvh<F, true>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                        sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst, small_run);
+                                       exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
                 else
                     hipLaunchKernelGGL((k_trace_samples_bvh<F, false>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                        sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst, small_run);
+                                       exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
             } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                    sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
