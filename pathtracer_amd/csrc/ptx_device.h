@@ -224,6 +224,9 @@ struct Rng {
 //           was pushed (RI_ONE: the initial 1.0 of initRay; RI_ZERO: never written)
 // 6 double + 10 int slots = 5.5 KiB per wave.
 enum { LS_SRCN = 0, LS_PRIMARY_D = 3, LS_DSLOTS = 6 };
+// further slots of the render kernels: LS_PARKED, colours of up to three finished samples waiting for their line's
+// fourth; LS_PEND (hierarchy kernel only), the part of an explicit light sample that waits in LDS for its shadow query
+enum { LS_PARKED = LS_DSLOTS, LS_PEND = LS_PARKED + 9, LS_PEND_N = 5 };
 enum { LS_RINDEX = 0, LS_ISLOTS = 10 };
 enum { RI_ONE = -1, RI_ZERO = -2 };
 struct LaneStore {
@@ -1100,7 +1103,10 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
 //   apply_shadow() what follows that second query (:428-445).
 // Same operations in the same order as bounce(), so both give the same bits.
 enum { SH_END = 0, SH_NEXT = 1, SH_SHADOW = 2 };
-// What the explicit light sample keeps while its shadow query runs.
+// What the explicit light sample keeps while its shadow query runs.  shade_hit leaves n_ed, rcp_d2, inv_keep, cr and cg
+// in the lane's LDS slots LS_PEND.. at the point where it computes them (shadow_pending_load fetches them for
+// apply_shadow) and returns only ed and cb in registers: the walk and the primitive tests of the query need the
+// registers, and values that the compiler moves to scratch memory instead cost a store to device memory each.
 struct ShadowPending {
     V3 ed;          // unit direction towards the sampled light point (the shadow ray starts at the path's new p0)
     double n_ed;    // n . ed
@@ -1151,7 +1157,32 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
     double dice = ps.rng.next();
     int next_os = h.obj;
     int result = SH_NEXT;
-    if (dice <= diffusivity) {
+    // one of three kinds of bounce, or none (reference PathTracer.c:336-428).  The code of the diffuse bounce comes
+    // last: what it leaves for the shadow query then does not have to survive the code of the other two.
+    const bool is_diffuse = dice <= diffusivity;
+    const bool is_mirror = !is_diffuse && dice <= diffusivity + reflectivity;
+    const bool is_refraction = !is_diffuse && !is_mirror && dice <= diffusivity + reflectivity + transparency;
+    if (is_mirror) {
+        if (rp.clean) ps.cel = 0;
+        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
+        n = norm3(n);
+        ps.d = reflect_dir(ps.d, n);
+        ps.p0 = p;
+        const double sig = mt.refl_sig;
+        if (sig > 0) glossy = sig;
+    }
+    if (is_refraction) {
+        if (rp.clean) ps.cel = 0;
+        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
+        refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
+        next_os = -1;
+    }
+    if (sc.has_refraction) {
+        ls.put(LS_SRCN + 0, n.x);
+        ls.put(LS_SRCN + 1, n.y);
+        ls.put(LS_SRCN + 2, n.z);
+    }
+    if (is_diffuse) {
         V3 dir;
         double scale;
         if (FLAGS & PTX_USE_IS) {
@@ -1176,37 +1207,27 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
             pend.ed = dl * fast_rsqrt(d2);
-            pend.n_ed = dot3(n, pend.ed);
-            pend.rcp_d2 = fast_rcp(d2);
-            pend.cr = ps.col.x * R;
-            pend.cg = ps.col.y * G;
+            ls.put(LS_PEND + 0, dot3(n, pend.ed));
+            ls.put(LS_PEND + 1, fast_rcp(d2));
+            ls.put(LS_PEND + 2, inv_keep);
+            ls.put(LS_PEND + 3, ps.col.x * R);
+            ls.put(LS_PEND + 4, ps.col.y * G);
             pend.cb = ps.col.z * B;
-            pend.inv_keep = inv_keep;
             result = SH_SHADOW;
         }
-    } else if (dice <= diffusivity + reflectivity) {
-        if (rp.clean) ps.cel = 0;
-        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        n = norm3(n);
-        ps.d = reflect_dir(ps.d, n);
-        ps.p0 = p;
-        const double sig = mt.refl_sig;
-        if (sig > 0) glossy = sig;
-    } else if (dice <= diffusivity + reflectivity + transparency) {
-        if (rp.clean) ps.cel = 0;
-        ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
-        next_os = -1;
-    }
-    if (sc.has_refraction) {
-        ls.put(LS_SRCN + 0, n.x);
-        ls.put(LS_SRCN + 1, n.y);
-        ls.put(LS_SRCN + 2, n.z);
     }
     ps.os = next_os;
     ps.depth++;
     over = ps.depth > rp.max_depth;
     return (result == SH_NEXT && over) ? SH_END : result;
+}
+
+__device__ __forceinline__ void shadow_pending_load(const LaneStore &ls, ShadowPending &pend) {
+    pend.n_ed = ls.get(LS_PEND + 0);
+    pend.rcp_d2 = ls.get(LS_PEND + 1);
+    pend.inv_keep = ls.get(LS_PEND + 2);
+    pend.cr = ls.get(LS_PEND + 3);
+    pend.cg = ls.get(LS_PEND + 4);
 }
 
 // sh: result of the shadow query from ps.p0 along pend.ed (os = ps.os).  Reference PathTracer.c:428-445.

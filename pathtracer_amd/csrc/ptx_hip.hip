@@ -54,7 +54,6 @@ template <int FLAGS, bool USE_BVH, bool PINHOLE>
 __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::waves_per_simd))
     k_trace_samples(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, size_t stride,
                     double *__restrict__ samples, unsigned long long *__restrict__ stats) {
-    enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
     __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
     const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
@@ -183,8 +182,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     k_trace_samples_bvh(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, int n_work, size_t stride,
                         double *__restrict__ samples, unsigned long long *__restrict__ stats, unsigned int *__restrict__ work_counter,
                         int exit_lanes, int leaf_batch, int shade_min, int burst, int small_run, int lds_nodes) {
-    enum { LS_PARKED = LS_DSLOTS };  // colours of up to three finished samples waiting for their line's fourth
-    __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
+    __shared__ double lds_d_[LS_PEND + LS_PEND_N][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
     const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
     const int lane = threadIdx.x & 63;
@@ -219,7 +217,8 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     Counters cnt = {0, 0, 0};
     uint32_t paths = 0;
     Path ps;
-    ShadowPending pend;
+    V3 shadow_d = mk(0, 0, 0);  // direction of the lane's shadow query
+    double shadow_cb = 0;       // the one field of its ShadowPending besides the direction that stays in registers
     Query q;
 #ifdef PTX_PHASE_TIMERS
     // per wave: cycles spent in each part of the loop, how often it ran and with how many lanes
@@ -261,6 +260,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
             if (n_shadow > 0 && (n_shadow >= small_run || shade_now || n_busy == 0)) {
                 DBG_BEGIN();
                 if (ready_shadow) {
+                    ShadowPending pend;
+                    pend.ed = shadow_d;
+                    pend.cb = shadow_cb;
+                    shadow_pending_load(ls, pend);
                     apply_shadow(sc, rp, ps, q.h, pend);
                     ended = over;
                     mode = M_CLOSEST;
@@ -273,10 +276,17 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
                 DBG_BEGIN();
                 double glossy = 0;
                 if (ready_closest) {
+                    ShadowPending pend;
+                    pend.ed = mk(0, 0, 0);
+                    pend.cb = 0;
                     const int r = shade_hit<FLAGS>(sc, rp, ls, ps, cnt, q.h, glossy, pend, over);
                     ended = r == SH_END;
                     mode = r == SH_SHADOW ? M_SHADOW : M_CLOSEST;
                     fresh = true;
+                    // (unconditional: a lane without a shadow query does not read them, and the old values do not
+                    // have to be kept through shade_hit)
+                    shadow_d = pend.ed;
+                    shadow_cb = pend.cb;
                 }
                 glossy_service(ps, glossy, lane);
                 DBG_END(D_SHADE, D_N_SHADE, D_L_SHADE, ready_closest);
@@ -392,7 +402,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
                 qd = ps.d;
             } else {
                 cnt.shadow++;
-                qd = pend.ed;
+                qd = shadow_d;
             }
             query_begin(sc, ps.p0, qd, ps.os, q);
             fresh = false;
@@ -417,7 +427,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
             const int n_step = __popcll(__ballot(stepping)), n_paused = __popcll(__ballot(paused));
             if (n_paused > 0 && (n_paused >= leaf_batch || n_step == 0)) {
                 DBG_BEGIN();
-                if (paused) query_leaf(sc, ps.p0, mode == M_SHADOW ? pend.ed : ps.d, q);
+                if (paused) query_leaf(sc, ps.p0, mode == M_SHADOW ? shadow_d : ps.d, q);
                 DBG_END(D_LEAF, D_N_LEAF, D_L_LEAF, paused);
                 continue;
             }
