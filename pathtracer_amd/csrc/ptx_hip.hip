@@ -1131,11 +1131,19 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     long fill = 16;
     if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
     // Scenes with a hierarchy: the kernel that carries queries in slices (PTX_BVH_KERNEL=whole selects the kernel
-    // that runs whole queries, for comparisons; the images are the same).  Its two settings were swept on SciFiCube
-    // and BubbleTea: leave the walk when at most exit_lanes lanes are still in it, test leaves leaf_batch at a time.
+    // that runs whole queries, for comparisons; the images are the same).  Its settings were swept at 2048 x 2048 on
+    // SciFiCube and BubbleTea (8000 and 6300 primitives in the hierarchy: node arrays of 4 MB, served by the L2 caches,
+    // the walk a quarter of the wave's time) and on the mesh scene of a million triangles (512 MB of nodes: a step
+    // waits for device memory and the walk is two thirds of the time).  What the second kind wants is many lanes
+    // walking at once, so it leaves the walk early to refill it (exit_lanes 24), shades smaller groups and takes
+    // short bursts: 1.43 times faster on that scene than with the first kind's settings, which in turn are 2 %
+    // better on the small scenes.
     bool sliced = true;
     if (const char *e = getenv("PTX_BVH_KERNEL")) sliced = strcmp(e, "whole") != 0;
-    int exit_lanes = 8, leaf_batch = 4, shade_min = 40, burst = 8, small_run = 8;
+    const size_t node_bytes = (size_t)c->sc.n_bvh_nodes * sizeof(PtxBvhNode) * (c->sc.bvh_per_octant ? 8 : 1);
+    const bool nodes_in_l2 = node_bytes <= ((size_t)32 << 20);  // eight L2 caches of 4 MB
+    int exit_lanes = nodes_in_l2 ? 12 : 24, leaf_batch = nodes_in_l2 ? 4 : 8, shade_min = nodes_in_l2 ? 40 : 24,
+        burst = nodes_in_l2 ? 6 : 4, small_run = 8;
     if (const char *e = getenv("PTX_WALK_EXIT_LANES")) exit_lanes = std::max(0, std::min(63, atoi(e)));
     if (const char *e = getenv("PTX_WALK_LEAF_BATCH")) leaf_batch = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("PTX_WALK_SHADE_MIN")) shade_min = std::max(1, std::min(64, atoi(e)));

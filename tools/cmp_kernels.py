@@ -12,8 +12,12 @@ if os.environ.get("PTX_LIB"):  # an alternative build of the library, for A/B me
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 variants = sys.argv[3:] or ["whole", "sliced"]
-for name, depth, ap in (("scifi", 12, 0.05), ("bubbletea", 12, 0.15)):
-    sc = Scene.load(os.path.join(REPO, "tests/golden", f"{name}_scene.npz"))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from walk_stats import load_scene
+ALL = {"scifi": (12, 0.05), "bubbletea": (12, 0.15), "meshstress": (8, 0.0)}
+for name in os.environ.get("PTX_CMP_SCENES", "scifi,bubbletea").split(","):  # PTX_CMP_SCENES=meshstress for the mesh configuration
+    depth, ap = ALL[name]
+    sc = load_scene(name)
     dev = pt.Device(0); dev.scene_upload(sc)
     ref = None
     for v in variants:

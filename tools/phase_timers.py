@@ -12,13 +12,14 @@ import pathtracer_amd as pt
 from pathtracer_amd import device
 
 device._LIB = device.load_library(os.path.join(REPO, "pathtracer_amd", "lib", "libptx_hip_dbg.so"))
-CONFIGS = {"cornell": (6, 0.0), "scifi": (12, 0.05), "bubbletea": (12, 0.15)}
+CONFIGS = {"cornell": (6, 0.0), "scifi": (12, 0.05), "bubbletea": (12, 0.15), "meshstress": (8, 0.0)}
 name, size, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 kernel = sys.argv[4] if len(sys.argv) > 4 else "sliced"
 os.environ["PTX_BVH_KERNEL"] = kernel
 depth, ap = CONFIGS[name]
-path = "cornell.ptxscene" if name == "cornell" else f"{name}_scene.npz"
-sc = pt.Scene.load(os.path.join(REPO, "tests", "golden", path))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from walk_stats import load_scene
+sc = load_scene(name)
 dev = pt.Device(0)
 dev.scene_upload(sc)
 dev.render_begin(pt.make_params(size, depth, 7, ap, seed=3))

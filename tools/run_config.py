@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders one of the larger benchmark configurations on one GPU in 25-pass launches (as the command line does) and
-prints throughput.  usage: run_config.py scifi|bubbletea [size spp]"""
+prints throughput.  usage: run_config.py scifi|bubbletea|meshstress [size spp]"""
 import os
 import sys
 import time
@@ -11,12 +11,14 @@ import numpy as np
 
 import pathtracer_amd as pt
 
-CONFIGS = {"scifi": (2048, 12, 400, 0.05), "bubbletea": (2048, 12, 2000, 0.15)}
+CONFIGS = {"scifi": (2048, 12, 400, 0.05), "bubbletea": (2048, 12, 2000, 0.15), "meshstress": (2048, 8, 100, 0.0)}
 name = sys.argv[1]
 sx, depth, spp, ap = CONFIGS[name]
 if len(sys.argv) > 3:
     sx, spp = int(sys.argv[2]), int(sys.argv[3])
-scene = pt.Scene.load(os.path.join(REPO, "tests", "golden", f"{name}_scene.npz"))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from walk_stats import load_scene
+scene = load_scene(name)
 dev = pt.Device(0)
 dev.scene_upload(scene)
 prm = pt.make_params(sx, depth, 7, ap, seed=1)
