@@ -388,6 +388,112 @@ __device__ __forceinline__ double isect_triangle(MP m, V3 p0, V3 d, int &part) {
     return -1.0;
 }
 
+// ---- the same intersectors without branches, for the always-tested list of the hierarchy kernel
+// There a primitive is tested by (nearly) all lanes of a wave at once and its record arrives by scalar loads.  The
+// early returns above save such a wave nothing (some lane always goes on), and they cut the routine into blocks, each
+// of which asks for its part of the record only when it is reached and then waits for it: three waits in a row for a
+// plane.  Written as one block, the record is asked for once, at the top.  Every lane computes what the routines above
+// compute on the path it would take there, so a hit has the same bits; where they return early these compute on
+// (possibly with infinities or NaNs, which no comparison accepts) and discard the result.
+template <typename MP>
+__device__ __forceinline__ double isect_sphere_nb(MP m, V3 p0, V3 d) {
+    V3 tp = xform_point(m, p0), td = xform_dir(m, d);
+    double A = dot3(td, td), B = dot3(tp, td), C = dot3(tp, tp) - 1.0;
+    double disc = B * B - A * C;
+    double sq = fast_sqrt(disc);
+    const double inv_a = fast_rcp(A);
+    double mb = -B * inv_a, sa = sq * inv_a;
+    const double r = sphere_roots(mb + sa, mb - sa);
+    return disc < 0.0 ? -1.0 : r;
+}
+template <typename GP>
+__device__ __forceinline__ double isect_sphere_uniform_nb(GP g, V3 p0, V3 d, double dd, double inv_dd) {
+    V3 oc = mk(p0.x - g->c[0], p0.y - g->c[1], p0.z - g->c[2]);
+    double B = dot3(oc, d), C = dot3(oc, oc) - g->e[0];
+    double disc = B * B - dd * C;
+    double sq = fast_sqrt(disc);
+    double t2 = -B - sq;
+    const double r = (t2 > PT_TOL * dd ? t2 : sq - B) * inv_dd;
+    return disc < 0.0 ? -1.0 : r;
+}
+template <typename MP>
+__device__ __forceinline__ double isect_plane_nb(MP m, V3 p0, V3 d) {
+    V3 tp = xform_point(m, p0), td = xform_dir(m, d);
+    double lam = -tp.z * fast_rcp(td.z);
+    const bool ok = !(fabs(td.z) < PT_TOL) & (fabs(tp.x + lam * td.x) <= 1.0 - PT_TOL) & (fabs(tp.y + lam * td.y) <= 1.0 - PT_TOL);
+    return ok ? lam : -1.0;
+}
+template <typename MP>
+__device__ __forceinline__ double isect_box_nb(MP m, V3 p0, V3 d, int &part) {
+    V3 tp = xform_point(m, p0), td = xform_dir(m, d);
+    double best = INFINITY;
+    part = -1;
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+        const int a = 2 - (f >> 1);
+        const double s = (f & 1) ? -1.0 : 1.0;
+        double da = comp(td, a), pa = comp(tp, a);
+        double lam = (s - pa) * fast_rcp(da);
+        const int b = (a + 1) % 3, c = (a + 2) % 3;
+        const bool ok = !(fabs(da) < PT_TOL) & (fabs(comp(tp, b) + lam * comp(td, b)) <= 1.0 - PT_TOL) &
+                        (fabs(comp(tp, c) + lam * comp(td, c)) <= 1.0 - PT_TOL) & (lam > PT_TOL) & (lam < best);
+        best = ok ? lam : best;
+        part = ok ? f : part;
+    }
+    return part < 0 ? -1.0 : best;
+}
+template <typename MP>
+__device__ __forceinline__ double isect_cyl_nb(MP m, V3 p0, V3 d, int &part) {
+    V3 tp = xform_point(m, p0), td = xform_dir(m, d);
+    double best = INFINITY;
+    part = -1;
+    double A = td.x * td.x + td.y * td.y;
+    double B = 2 * tp.x * td.x + 2 * tp.y * td.y;
+    double C = tp.x * tp.x + tp.y * tp.y - 1;
+    double det = B * B - 4 * A * C;
+    const bool wall = !(det < 0);
+    const double sq = fast_sqrt(det), inv_2a = fast_rcp(2 * A);
+    double l1 = (-1 * B + sq) * inv_2a;
+    double l2 = (-1 * B - sq) * inv_2a;
+    const bool ok1 = wall & (fabs(tp.z + l1 * td.z) <= 1) & (l1 > PT_TOL) & (best > l1);
+    best = ok1 ? l1 : best;
+    part = ok1 ? 0 : part;
+    const bool ok2 = wall & (fabs(tp.z + l2 * td.z) <= 1) & (l2 > PT_TOL) & (best > l2);
+    best = ok2 ? l2 : best;
+    part = ok2 ? 0 : part;
+    const double inv_dz = fast_rcp(td.z);
+    double c1 = (-1 - tp.z) * inv_dz;
+    double c2 = (1 - tp.z) * inv_dz;
+    {
+        double x = tp.x + c1 * td.x, y = tp.y + c1 * td.y;
+        const bool ok = (x * x + y * y <= 1) & (c1 > PT_TOL) & (best > c1);
+        best = ok ? c1 : best;
+        part = ok ? 1 : part;
+    }
+    {
+        double x = tp.x + c2 * td.x, y = tp.y + c2 * td.y;
+        const bool ok = (x * x + y * y <= 1) & (c2 > PT_TOL) & (best > c2);
+        best = ok ? c2 : best;
+        part = ok ? 2 : part;
+    }
+    return part < 0 ? -1.0 : best;
+}
+template <typename MP>
+__device__ __forceinline__ double isect_triangle_nb(MP m, V3 p0, V3 d, int &part) {
+    V3 p1 = mk(m[0], m[1], m[2]), p2 = mk(m[3], m[4], m[5]), p3 = mk(m[6], m[7], m[8]);
+    V3 n = mk(m[9], m[10], m[11]);
+    double ddn = dot3(n, d);
+    part = ddn > 0 ? 1 : 0;
+    double lam = dot3(p1 - p0, n) * fast_rcp(ddn);
+    V3 poi = p0 + d * lam;
+    V3 e12 = p2 - p1, e23 = p3 - p2, e31 = p1 - p3, e13 = p3 - p1, e32 = p2 - p3, e21 = p1 - p2;
+    double v1 = dot3(cross3(poi - p1, e12), cross3(e13, e12));
+    double v2 = dot3(cross3(poi - p2, e23), cross3(e21, e23));
+    double v3 = dot3(cross3(poi - p3, e31), cross3(e32, e31));
+    const bool ok = !((-PT_TOL < ddn) & (ddn < PT_TOL)) & (lam > 0) & (v1 >= 0) & (v2 >= 0) & (v3 >= 0);
+    return ok ? lam : -1.0;
+}
+
 struct Hit {
     double lambda;
     int obj;
@@ -1293,6 +1399,9 @@ __device__ __forceinline__ void query_axis32(double p, float i, float bound, flo
     near_o = __double2float_ru(o + e);
     far_o = __double2float_rd(o - e);
 }
+#ifndef PTX_LIST_UNROLL
+#define PTX_LIST_UNROLL 2  // trips of the list loops unrolled (measured: 2 is 3 % better than 1 on BubbleTea)
+#endif
 __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int os, Query &q) {
     q.h.lambda = INFINITY;
     q.h.obj = -1;
@@ -1306,29 +1415,34 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
     const ConstGeomPtr cg = (ConstGeomPtr)sc.class_geom;
     const PTX_CONSTANT_AS int32_t *ids = (const PTX_CONSTANT_AS int32_t *)sc.class_ids;
     auto take = [&](int id, double lam, int part) {
-        if (id != os && lam > PT_TOL && (lam < q.h.lambda || (lam == q.h.lambda && id < q.h.obj))) {
-            q.h.lambda = lam;
-            q.h.obj = id;
-            q.h.part = part;
-        }
+        const bool win = (id != os) & (lam > PT_TOL) & ((lam < q.h.lambda) | ((lam == q.h.lambda) & (id < q.h.obj)));
+        q.h.lambda = win ? lam : q.h.lambda;
+        q.h.obj = win ? id : q.h.obj;
+        q.h.part = win ? part : q.h.part;
     };
     int k = 0;
-    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform(cg + k, p0, d, dd, inv_dd), 0);
-    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere(&cg[k].m[0], p0, d), 0);
-    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane(&cg[k].m[0], p0, d), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform_nb(cg + k, p0, d, dd, inv_dd), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere_nb(&cg[k].m[0], p0, d), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane_nb(&cg[k].m[0], p0, d), 0);
+#pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_TRIANGLE]; k++) {
         int part;
-        const double lam = isect_triangle(&cg[k].m[0], p0, d, part);
+        const double lam = isect_triangle_nb(&cg[k].m[0], p0, d, part);
         take(ids[k], lam, part);
     }
+#pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_CYL]; k++) {
         int part;
-        const double lam = isect_cyl(&cg[k].m[0], p0, d, part);
+        const double lam = isect_cyl_nb(&cg[k].m[0], p0, d, part);
         take(ids[k], lam, part);
     }
+#pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_BOX]; k++) {
         int part;
-        const double lam = isect_box(&cg[k].m[0], p0, d, part);
+        const double lam = isect_box_nb(&cg[k].m[0], p0, d, part);
         take(ids[k], lam, part);
     }
     q.best = __double2float_ru(q.h.lambda);
