@@ -522,6 +522,51 @@ __device__ __forceinline__ double isect_any(GP g, V3 p0, V3 d, double dd, double
     return isect_typed(g, g->type, g->fast, p0, d, dd, inv_dd, part);
 }
 
+#ifndef PTX_LIST_UNROLL
+#define PTX_LIST_UNROLL 2  // trips of the list loops unrolled (measured: 2 is 3 % better than 1 on BubbleTea)
+#endif
+// The always-tested primitives against one ray, group by group (DevScene::class_geom): h receives the closest hit
+// among them if it beats the one h holds.
+__device__ __forceinline__ void list_hits_nb(const DevScene &sc, V3 p0, V3 d, int os, double dd, double inv_dd, Hit &h) {
+    // The always-tested primitives, group by group: a loop that knows its intersection routine asks for the part
+    // of the record it needs without first waiting for the record's type (the records arrive by scalar loads, and
+    // a wave has little else to do while it waits for one).  Equal lambdas go to the lower scene index, as in
+    // closest_hit_all, where the primitives are tested in that order.
+    const ConstGeomPtr cg = (ConstGeomPtr)sc.class_geom;
+    const PTX_CONSTANT_AS int32_t *ids = (const PTX_CONSTANT_AS int32_t *)sc.class_ids;
+    auto take = [&](int id, double lam, int part) {
+        const bool win = (id != os) & (lam > PT_TOL) & ((lam < h.lambda) | ((lam == h.lambda) & (id < h.obj)));
+        h.lambda = win ? lam : h.lambda;
+        h.obj = win ? id : h.obj;
+        h.part = win ? part : h.part;
+    };
+    int k = 0;
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform_nb(cg + k, p0, d, dd, inv_dd), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere_nb(&cg[k].m[0], p0, d), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane_nb(&cg[k].m[0], p0, d), 0);
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_TRIANGLE]; k++) {
+        int part;
+        const double lam = isect_triangle_nb(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
+    }
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_CYL]; k++) {
+        int part;
+        const double lam = isect_cyl_nb(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
+    }
+#pragma unroll PTX_LIST_UNROLL
+    for (; k < sc.class_end[LC_BOX]; k++) {
+        int part;
+        const double lam = isect_box_nb(&cg[k].m[0], p0, d, part);
+        take(ids[k], lam, part);
+    }
+}
+
 // findFirstHit (reference PathTracer.c:198-251): the smallest lambda > TOL wins and, between equal lambdas, the
 // primitive the reference visits first (the lower scene index).
 //  - The always-tested list is walked with a wave-uniform index, so its records arrive through scalar loads and
@@ -552,6 +597,12 @@ __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, 
 #ifdef PTX_PHASE_TIMERS
     long long tm0 = COUNT ? clock64() : 0;
 #endif
+    if (!USE_BVH) {
+        // a scene without a hierarchy: all its primitives, group by group (0.6 % faster on the Cornell box than the
+        // loop below, which has to wait for a record's type before it can ask for the rest)
+        list_hits_nb(sc, p0, d, os, dd, inv_dd, h);
+        if (COUNT) wc->list_tests += sc.n_list;
+    } else
     for (int k = 0; k < sc.n_list; k++) {
         int part;
         const int id = USE_BVH ? list_ids[k] : k;
@@ -1399,52 +1450,13 @@ __device__ __forceinline__ void query_axis32(double p, float i, float bound, flo
     near_o = __double2float_ru(o + e);
     far_o = __double2float_rd(o - e);
 }
-#ifndef PTX_LIST_UNROLL
-#define PTX_LIST_UNROLL 2  // trips of the list loops unrolled (measured: 2 is 3 % better than 1 on BubbleTea)
-#endif
 __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int os, Query &q) {
     q.h.lambda = INFINITY;
     q.h.obj = -1;
     q.h.part = 0;
     const double dd = dot3(d, d);
     const double inv_dd = fast_rcp(dd);
-    // The always-tested primitives, group by group: a loop that knows its intersection routine asks for the part
-    // of the record it needs without first waiting for the record's type (the records arrive by scalar loads, and
-    // a wave has little else to do while it waits for one).  Equal lambdas go to the lower scene index, as in
-    // closest_hit_all, where the primitives are tested in that order.
-    const ConstGeomPtr cg = (ConstGeomPtr)sc.class_geom;
-    const PTX_CONSTANT_AS int32_t *ids = (const PTX_CONSTANT_AS int32_t *)sc.class_ids;
-    auto take = [&](int id, double lam, int part) {
-        const bool win = (id != os) & (lam > PT_TOL) & ((lam < q.h.lambda) | ((lam == q.h.lambda) & (id < q.h.obj)));
-        q.h.lambda = win ? lam : q.h.lambda;
-        q.h.obj = win ? id : q.h.obj;
-        q.h.part = win ? part : q.h.part;
-    };
-    int k = 0;
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform_nb(cg + k, p0, d, dd, inv_dd), 0);
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere_nb(&cg[k].m[0], p0, d), 0);
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane_nb(&cg[k].m[0], p0, d), 0);
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_TRIANGLE]; k++) {
-        int part;
-        const double lam = isect_triangle_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
-    }
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_CYL]; k++) {
-        int part;
-        const double lam = isect_cyl_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
-    }
-#pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_BOX]; k++) {
-        int part;
-        const double lam = isect_box_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
-    }
+    list_hits_nb(sc, p0, d, os, dd, inv_dd, q.h);
     q.best = __double2float_ru(q.h.lambda);
     q.ix = rcp_for_slab32(d.x);
     q.iy = rcp_for_slab32(d.y);
