@@ -6,5 +6,5 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SIZE=$1; SPP=$2; shift 2
 for L in "$@"; do
   echo "== $L"
-  PTX_LIB=$ROOT/pathtracer_amd/lib/$L timeout -k 10 300 python3 $ROOT/tools/cmp_kernels.py $SIZE $SPP sliced sliced 2>&1 | tail -4
+  PTX_LIB=$ROOT/pathtracer_amd/lib/$L timeout -k 10 300 python3 $ROOT/tools/cmp_kernels.py $SIZE $SPP whole sliced sliced 2>&1 | tail -9
 done

@@ -1,6 +1,6 @@
 """Times the render kernels for hierarchy scenes against each other and checks that their images are equal.
 usage: cmp_kernels.py size spp [whole | sliced[:exit_lanes,leaf_batch,shade_min,burst,small_run]] ..."""
-import os, sys, time
+import hashlib, os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -36,5 +36,5 @@ for name in os.environ.get("PTX_CMP_SCENES", "scifi,bubbletea").split(","):  # P
         rgb, w = dev.download(); st = dev.stats()
         same = "" if ref is None else f" same_as_first={np.array_equal(rgb, ref[0], equal_nan=True) and np.array_equal(w, ref[1], equal_nan=True) and st == ref[2]}"
         if ref is None: ref = (rgb, w, st)
-        print(f"{name} {size}^2 {spp}spp {v}: {dt*1e3:.1f} ms, {size*size*spp/dt/1e6:.1f} M paths/s{same}", flush=True)
+        print(f"{name} {size}^2 {spp}spp {v}: {dt*1e3:.1f} ms, {size*size*spp/dt/1e6:.1f} M paths/s, image sha {hashlib.sha1(rgb.tobytes() + w.tobytes()).hexdigest()[:10]}{same}", flush=True)
     dev.close()
