@@ -395,33 +395,37 @@ __device__ __forceinline__ double isect_triangle(MP m, V3 p0, V3 d, int &part) {
 // plane.  Written as one block, the record is asked for once, at the top.  Every lane computes what the routines above
 // compute on the path it would take there, so a hit has the same bits; where they return early these compute on
 // (possibly with infinities or NaNs, which no comparison accepts) and discard the result.
+// `hit` (or `missed`): whether the value returned means anything; the caller folds it into its own test instead of having
+// a -1 selected here.  The box and cylinder routines return infinity for "nothing", which no test accepts.
 template <typename MP>
-__device__ __forceinline__ double isect_sphere_nb(MP m, V3 p0, V3 d) {
+__device__ __forceinline__ double isect_sphere_nb(MP m, V3 p0, V3 d, bool &hit) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double A = dot3(td, td), B = dot3(tp, td), C = dot3(tp, tp) - 1.0;
     double disc = B * B - A * C;
     double sq = fast_sqrt(disc);
     const double inv_a = fast_rcp(A);
     double mb = -B * inv_a, sa = sq * inv_a;
-    const double r = sphere_roots(mb + sa, mb - sa);
-    return disc < 0.0 ? -1.0 : r;
+    hit = !(disc < 0.0);
+    return sphere_roots(mb + sa, mb - sa);
 }
+// missed: the ray's line does not meet the sphere; the value returned is then meaningless (the caller tests `missed`
+// instead of having a -1 selected here)
 template <typename GP>
-__device__ __forceinline__ double isect_sphere_uniform_nb(GP g, V3 p0, V3 d, double dd, double inv_dd) {
+__device__ __forceinline__ double isect_sphere_uniform_nb(GP g, V3 p0, V3 d, double dd, double inv_dd, bool &missed) {
     V3 oc = mk(p0.x - g->c[0], p0.y - g->c[1], p0.z - g->c[2]);
     double B = dot3(oc, d), C = dot3(oc, oc) - g->e[0];
     double disc = B * B - dd * C;
     double sq = fast_sqrt(disc);
     double t2 = -B - sq;
-    const double r = (t2 > PT_TOL * dd ? t2 : sq - B) * inv_dd;
-    return disc < 0.0 ? -1.0 : r;
+    missed = disc < 0.0;
+    return (t2 > PT_TOL * dd ? t2 : sq - B) * inv_dd;
 }
 template <typename MP>
-__device__ __forceinline__ double isect_plane_nb(MP m, V3 p0, V3 d) {
+__device__ __forceinline__ double isect_plane_nb(MP m, V3 p0, V3 d, bool &hit) {
     V3 tp = xform_point(m, p0), td = xform_dir(m, d);
     double lam = -tp.z * fast_rcp(td.z);
-    const bool ok = !(fabs(td.z) < PT_TOL) & (fabs(tp.x + lam * td.x) <= 1.0 - PT_TOL) & (fabs(tp.y + lam * td.y) <= 1.0 - PT_TOL);
-    return ok ? lam : -1.0;
+    hit = !(fabs(td.z) < PT_TOL) & (fabs(tp.x + lam * td.x) <= 1.0 - PT_TOL) & (fabs(tp.y + lam * td.y) <= 1.0 - PT_TOL);
+    return lam;
 }
 template <typename MP>
 __device__ __forceinline__ double isect_box_nb(MP m, V3 p0, V3 d, int &part) {
@@ -440,7 +444,7 @@ __device__ __forceinline__ double isect_box_nb(MP m, V3 p0, V3 d, int &part) {
         best = ok ? lam : best;
         part = ok ? f : part;
     }
-    return part < 0 ? -1.0 : best;
+    return best;
 }
 template <typename MP>
 __device__ __forceinline__ double isect_cyl_nb(MP m, V3 p0, V3 d, int &part) {
@@ -476,10 +480,10 @@ __device__ __forceinline__ double isect_cyl_nb(MP m, V3 p0, V3 d, int &part) {
         best = ok ? c2 : best;
         part = ok ? 2 : part;
     }
-    return part < 0 ? -1.0 : best;
+    return best;
 }
 template <typename MP>
-__device__ __forceinline__ double isect_triangle_nb(MP m, V3 p0, V3 d, int &part) {
+__device__ __forceinline__ double isect_triangle_nb(MP m, V3 p0, V3 d, int &part, bool &hit) {
     V3 p1 = mk(m[0], m[1], m[2]), p2 = mk(m[3], m[4], m[5]), p3 = mk(m[6], m[7], m[8]);
     V3 n = mk(m[9], m[10], m[11]);
     double ddn = dot3(n, d);
@@ -490,8 +494,8 @@ __device__ __forceinline__ double isect_triangle_nb(MP m, V3 p0, V3 d, int &part
     double v1 = dot3(cross3(poi - p1, e12), cross3(e13, e12));
     double v2 = dot3(cross3(poi - p2, e23), cross3(e21, e23));
     double v3 = dot3(cross3(poi - p3, e31), cross3(e32, e31));
-    const bool ok = !((-PT_TOL < ddn) & (ddn < PT_TOL)) & (lam > 0) & (v1 >= 0) & (v2 >= 0) & (v3 >= 0);
-    return ok ? lam : -1.0;
+    hit = !((-PT_TOL < ddn) & (ddn < PT_TOL)) & (lam > 0) & (v1 >= 0) & (v2 >= 0) & (v3 >= 0);
+    return lam;
 }
 
 struct Hit {
@@ -534,36 +538,54 @@ __device__ __forceinline__ void list_hits_nb(const DevScene &sc, V3 p0, V3 d, in
     // closest_hit_all, where the primitives are tested in that order.
     const ConstGeomPtr cg = (ConstGeomPtr)sc.class_geom;
     const PTX_CONSTANT_AS int32_t *ids = (const PTX_CONSTANT_AS int32_t *)sc.class_ids;
-    auto take = [&](int id, double lam, int part) {
-        const bool win = (id != os) & (lam > PT_TOL) & ((lam < h.lambda) | ((lam == h.lambda) & (id < h.obj)));
+    auto take = [&](int id, double lam, int part, bool hit) {
+        const bool win = hit & (id != os) & (lam > PT_TOL) & ((lam < h.lambda) | ((lam == h.lambda) & (id < h.obj)));
         h.lambda = win ? lam : h.lambda;
         h.obj = win ? id : h.obj;
         h.part = win ? part : h.part;
     };
     int k = 0;
+    // The first group meets an empty h and its members come in ascending scene index, so a strictly smaller lambda is
+    // the whole rule there: of two equal ones the first tested has the lower index.
 #pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) take(ids[k], isect_sphere_uniform_nb(cg + k, p0, d, dd, inv_dd), 0);
+    for (; k < sc.class_end[LC_FAST_SPHERE]; k++) {
+        bool missed;
+        const double lam = isect_sphere_uniform_nb(cg + k, p0, d, dd, inv_dd, missed);
+        const int id = ids[k];
+        const bool win = !missed & (id != os) & (lam > PT_TOL) & (lam < h.lambda);
+        h.lambda = win ? lam : h.lambda;
+        h.obj = win ? id : h.obj;
+    }
 #pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_SPHERE]; k++) take(ids[k], isect_sphere_nb(&cg[k].m[0], p0, d), 0);
+    for (; k < sc.class_end[LC_SPHERE]; k++) {
+        bool hit;
+        const double lam = isect_sphere_nb(&cg[k].m[0], p0, d, hit);
+        take(ids[k], lam, 0, hit);
+    }
 #pragma unroll PTX_LIST_UNROLL
-    for (; k < sc.class_end[LC_PLANE]; k++) take(ids[k], isect_plane_nb(&cg[k].m[0], p0, d), 0);
+    for (; k < sc.class_end[LC_PLANE]; k++) {
+        bool hit;
+        const double lam = isect_plane_nb(&cg[k].m[0], p0, d, hit);
+        take(ids[k], lam, 0, hit);
+    }
 #pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_TRIANGLE]; k++) {
         int part;
-        const double lam = isect_triangle_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
+        bool hit;
+        const double lam = isect_triangle_nb(&cg[k].m[0], p0, d, part, hit);
+        take(ids[k], lam, part, hit);
     }
 #pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_CYL]; k++) {
         int part;
         const double lam = isect_cyl_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
+        take(ids[k], lam, part, true);
     }
 #pragma unroll PTX_LIST_UNROLL
     for (; k < sc.class_end[LC_BOX]; k++) {
         int part;
         const double lam = isect_box_nb(&cg[k].m[0], p0, d, part);
-        take(ids[k], lam, part);
+        take(ids[k], lam, part, true);
     }
 }
 
