@@ -1,6 +1,6 @@
 /*
  * ref_gpu_cli.c -- TEST INFRASTRUCTURE.  The reference program with its sample loop swapped for the GPU library,
- * as INTEGRATION.md describes for a maintainer: the reference's own scene construction, BoxTree, light weights and
+ * the way a maintainer of the reference would do it: the reference's own scene construction, BoxTree, light weights and
  * dataOutput (compiled from /root/reference by oracle/Makefile), integration/ref_flatten.c and
  * integration/ref_gpu_loop.c in between.  This main() repeats the set-up steps of the reference's main()
  * (PathTracer.c:521-611) by calling the reference's functions; it exists because that main() cannot be edited

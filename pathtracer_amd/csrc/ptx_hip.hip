@@ -34,6 +34,60 @@
 // instructions traced.
 #define PTX_SAMPLE_DOUBLES 4
 
+// One sample folded into a pixel's accumulator (reference PathTracer.c:646-652)
+__device__ __forceinline__ void fold_sample(double &ar, double &ag, double &ab, double &wt, double cr, double cg, double cb) {
+    const double f = exp2(-lean_log(wt));
+    ar += cr * f;
+    ag += cg * f;
+    ab += cb * f;
+    wt += cr;
+    wt += cg;
+    wt += cb;
+}
+
+// The samples 0 .. n_samples-1 of one pixel folded into its accumulator, in sample order: four samples (one 128-byte line
+// of the pixel's stream) per trip.  linear: PTX_CLEAN's accumulator instead of the reference's, rgb += colour, wght += 1.
+__device__ __forceinline__ void fold_pixel(const double *samples, size_t pix, size_t stride, int n_samples, double *rgb, double *wght,
+                                           int linear) {
+    double ar = rgb[pix * 3 + 0], ag = rgb[pix * 3 + 1], ab = rgb[pix * 3 + 2], wt = wght[pix];
+    const double4 *in = (const double4 *)(samples + pix * stride * PTX_SAMPLE_DOUBLES);
+    int q = 0;
+    if (linear) {
+        for (; q < n_samples; q++) {
+            const double4 s0 = in[q];
+            ar += s0.x;
+            ag += s0.y;
+            ab += s0.z;
+        }
+        wt += (double)n_samples;
+    }
+    if (q + 4 <= n_samples) {
+        // the next line is on its way while this one is folded
+        double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
+        for (; q + 8 <= n_samples; q += 4) {
+            const double4 t0 = in[q + 4], t1 = in[q + 5], t2 = in[q + 6], t3 = in[q + 7];
+            fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
+            fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
+            fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
+            fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
+            s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+        }
+        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
+        fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
+        fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
+        fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
+        q += 4;
+    }
+    for (; q < n_samples; q++) {
+        const double4 s0 = in[q];
+        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
+    }
+    rgb[pix * 3 + 0] = ar;
+    rgb[pix * 3 + 1] = ag;
+    rgb[pix * 3 + 2] = ab;
+    wght[pix] = wt;
+}
+
 // Waves per SIMD the trace kernel is compiled for.  The kernel for small scenes with a zero aperture (the benchmark
 // case) is held to 128 registers, a little below what it wants, and runs four waves per SIMD; the variants with a
 // hierarchy or a lens need more registers and lose 10 % that way: three waves.
@@ -52,7 +106,7 @@ struct TraceShape {
 // wave, a multiple of four.
 template <int FLAGS, bool USE_BVH, bool PINHOLE>
 __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::waves_per_simd))
-    k_trace_samples(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, size_t stride,
+    k_trace_samples(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_full, int tail_len, int n_tiles, size_t stride,
                     double *__restrict__ samples, unsigned long long *__restrict__ stats) {
     __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
@@ -66,8 +120,11 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
     const bool inside = i < rp.sx && jl < rp.rows_owned;
     const int j = inside ? ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows) : 0;
     const size_t pix = inside ? (size_t)jl * rp.sx + i : 0;
-    const int ks = k0 + sub * sub_len;
-    const int ke = inside ? (ks + sub_len < k1 ? ks + sub_len : k1) : ks;
+    // the first n_full ranges have sub_len samples, those after them tail_len: the waves the GPU runs last are short
+    // ones, so that its compute units run dry at about the same time
+    const int ks = sub < n_full ? k0 + sub * sub_len : k0 + n_full * sub_len + (sub - n_full) * tail_len;
+    const int my_len = sub < n_full ? sub_len : tail_len;
+    const int ke = inside ? (ks + my_len < k1 ? ks + my_len : k1) : ks;
 
     Counters cnt = {0, 0, 0};
     uint32_t paths = 0;
@@ -465,17 +522,6 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     }
 }
 
-// One sample folded into a pixel's accumulator (reference PathTracer.c:646-652)
-__device__ __forceinline__ void fold_sample(double &ar, double &ag, double &ab, double &wt, double cr, double cg, double cb) {
-    const double f = exp2(-lean_log(wt));
-    ar += cr * f;
-    ag += cg * f;
-    ab += cb * f;
-    wt += cr;
-    wt += cg;
-    wt += cb;
-}
-
 // The accumulation for n_samples samples of every pixel, in sample order; one lane per pixel, four samples (one
 // 128-byte line of the lane's own stream) per trip.
 // linear: PTX_CLEAN's accumulator instead of the reference's, rgb += colour and wght += 1.
@@ -483,33 +529,7 @@ __global__ void __launch_bounds__(256) k_fold_samples(const double *__restrict__
                                                        int n_samples, double *__restrict__ rgb, double *__restrict__ wght, int linear) {
     const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= n_pix) return;
-    double ar = rgb[pix * 3 + 0], ag = rgb[pix * 3 + 1], ab = rgb[pix * 3 + 2], wt = wght[pix];
-    const double4 *in = (const double4 *)(samples + pix * stride * PTX_SAMPLE_DOUBLES);
-    int q = 0;
-    if (linear) {
-        for (; q < n_samples; q++) {
-            const double4 s0 = in[q];
-            ar += s0.x;
-            ag += s0.y;
-            ab += s0.z;
-        }
-        wt += (double)n_samples;
-    }
-    for (; q + 4 <= n_samples; q += 4) {
-        const double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
-        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
-        fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
-        fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
-        fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
-    }
-    for (; q < n_samples; q++) {
-        const double4 s0 = in[q];
-        fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
-    }
-    rgb[pix * 3 + 0] = ar;
-    rgb[pix * 3 + 1] = ag;
-    rgb[pix * 3 + 2] = ab;
-    wght[pix] = wt;
+    fold_pixel(samples, pix, stride, n_samples, rgb, wght, linear);
 }
 
 template <int FLAGS, bool USE_BVH>
@@ -1159,6 +1179,18 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
         long n_sub = std::max(1L, std::min((fill * slots + n_tiles - 1) / n_tiles, (long)nka / 8));
         const int sub_len = (int)(((nka + n_sub - 1) / n_sub + 3) & ~3L);
         n_sub = (nka + sub_len - 1) / sub_len;
+        // k_trace_samples: the last of these ranges is cut into tail_split shorter ones.  Blocks start in the order of their
+        // index, so the waves that run while the GPU empties are short and it empties almost at once (PTX_TAIL_SPLIT
+        // overrides, 1: all ranges alike)
+        int n_full = (int)n_sub, tail_len = sub_len;
+        long tail_split = 2;
+        if (const char *e = getenv("PTX_TAIL_SPLIT")) tail_split = std::max(1L, atol(e));
+        if (!(c->use_bvh && sliced) && tail_split > 1 && n_sub >= 2) {
+            n_full = (int)n_sub - 1;
+            const long rest = nka - (long)n_full * sub_len;
+            tail_len = (int)(((rest + tail_split - 1) / tail_split + 3) & ~3L);
+            n_sub = n_full + (rest + tail_len - 1) / tail_len;
+        }
         if (n_tiles * n_sub > 0x7fffffffL) return fail(PTX_EINVAL, "ptx_render_passes: image too large for one launch");
         if (per_launch_timing) {
             while ((int)c->trace_ev.size() < 2 * (c->n_trace_launches + 1)) {
@@ -1187,10 +1219,10 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
                                        exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
             } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
+                                   sub_len, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
             else
                 hipLaunchKernelGGL((k_trace_samples<F, B, false>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
+                                   sub_len, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
         });
         HIPCHK(hipGetLastError());
         if (per_launch_timing) {

@@ -527,20 +527,20 @@ def test_texel_layout_does_not_change_results(name, scenes, monkeypatch):
 def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
     """A render_passes call traces its samples in as many rounds as the sample buffer needs and cuts each round
     into waves of whatever length fills the GPU; the accumulator is folded in sample order all the same, so the
-    image does not depend on either choice, bit for bit."""
+    image does not depend on either choice, bit for bit.  Nor on the number of shorter ranges the last range of a
+    round is cut into (the waves that run while the GPU empties)."""
     dev = gpu["cornell"]
     sx, spp = 72, 40
     prm = pt.make_params(sx, 6, ALL, 0.0, seed=12)
     got = []
-    for buffer_mb, waves_per_slot in ((None, None), ("1", None), (None, "1"), ("1", "64")):
-        if buffer_mb is None:
-            monkeypatch.delenv("PTX_SAMPLE_BUFFER_MB", raising=False)
-        else:
-            monkeypatch.setenv("PTX_SAMPLE_BUFFER_MB", buffer_mb)  # 1 MiB: 6 samples of 72 x 72 pixels, four to a round
-        if waves_per_slot is None:
-            monkeypatch.delenv("PTX_WAVES_PER_SLOT", raising=False)
-        else:
-            monkeypatch.setenv("PTX_WAVES_PER_SLOT", waves_per_slot)
+    for buffer_mb, waves_per_slot, tail_split in ((None, None, None), ("1", None, None), (None, "1", None), ("1", "64", None),
+                                                  (None, None, "1"), (None, None, "3"), (None, "2", "7"), (None, "64", "64")):
+        for var, val in (("PTX_SAMPLE_BUFFER_MB", buffer_mb),  # 1 MiB: 6 samples of 72 x 72 pixels, four to a round
+                         ("PTX_WAVES_PER_SLOT", waves_per_slot), ("PTX_TAIL_SPLIT", tail_split)):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
         dev.render_begin(prm)
         dev.render_passes(0, spp)
         rgb, w = dev.download()
