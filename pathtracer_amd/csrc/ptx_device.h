@@ -599,13 +599,37 @@ __device__ __forceinline__ void list_hits_nb(const DevScene &sc, V3 p0, V3 d, in
 //    boxes are a little larger than the reference's, which keeps rounding from rejecting one it would enter.
 // COUNT: the instrumented build -- wc receives how many list primitives, hierarchy nodes and leaf primitives (by
 // type) the query tested.
+#define PTX_N_PHASES 12
 struct WalkCount {
     uint32_t queries, hits, list_tests, node_visits, leaf_tests[6], texel_lookups;
 #ifdef PTX_PHASE_TIMERS
     long long cyc_list, cyc_walk, cyc_leaf;
     double steps_wave, leaf_passes_wave;  // loop trips as the wave sees them: every active lane adds 1/(active lanes)
+    // the parts of bounce() and of the loop of k_trace_samples around it (PH_*): cycles, runs and lanes of each, kept
+    // per wave in LDS (three counters a part; null: not counted) and updated by the first lane that is in the part
+    unsigned long long *ph;
 #endif
 };
+enum { PH_QUERY = 0, PH_SURFACE, PH_DIFFUSE, PH_LIGHT, PH_SHADOW_QUERY, PH_SHADOW_APPLY, PH_MIRROR, PH_REFRACT, PH_NEW_PATH, PH_GLOSSY,
+       PH_SAMPLE_END, PH_LOOP };
+#ifdef PTX_PHASE_TIMERS
+#define PH_T() (COUNT ? clock64() : 0LL)
+#define PH_ADD(wc, i, t0)                                                                  \
+    do {                                                                                   \
+        if (COUNT && (wc)->ph) {                                                           \
+            const long long dt_ = clock64() - (t0);                                        \
+            const unsigned long long m_ = __ballot(1);                                     \
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                   \
+                atomicAdd(&(wc)->ph[3 * (i)], (unsigned long long)dt_);                    \
+                atomicAdd(&(wc)->ph[3 * (i) + 1], 1ULL);                                   \
+                atomicAdd(&(wc)->ph[3 * (i) + 2], (unsigned long long)__popcll(m_));       \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+#else
+#define PH_T() 0LL
+#define PH_ADD(wc, i, t0) ((void)0)
+#endif
 template <bool USE_BVH, bool COUNT = false>
 __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os, WalkCount *wc = nullptr) {
     Hit h;
@@ -1161,10 +1185,13 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                               double &glossy, WalkCount *wc = nullptr) {
     const bool clean = ALLOW_CLEAN && rp.clean != 0;
     glossy = 0;
+    long long ph_t = PH_T();
     ps.d = norm3(ps.d);
     cnt.closest++;
     Hit h = closest_hit_all<USE_BVH, COUNT>(sc, ps.p0, ps.d, ps.os, wc);
+    PH_ADD(wc, PH_QUERY, ph_t);
     if (h.obj < 0) return true;
+    ph_t = PH_T();
     const DevMat &mt = sc.mat[h.obj];
     const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
     V3 p, n;
@@ -1197,7 +1224,9 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     const double inv_keep = (FLAGS & PTX_USE_RR) ? fast_rcp(1 - rr) : 1.0;
     double dice = ps.rng.next();
     int next_os = h.obj;
+    PH_ADD(wc, PH_SURFACE, ph_t);
     if (dice <= diffusivity) {
+        ph_t = PH_T();
         V3 dir;
         double scale;
         if (FLAGS & PTX_USE_IS) {
@@ -1210,7 +1239,9 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         ps.col = mk(ps.col.x * (R * scale), ps.col.y * (G * scale), ps.col.z * (B * scale));
         ps.p0 = p;
         ps.d = dir;
+        PH_ADD(wc, PH_DIFFUSE, ph_t);
         if (FLAGS & PTX_USE_ES) {
+            ph_t = PH_T();
             double u = ps.rng.next();
             int li = 0;
             double acc = sc.lights[0].weight;
@@ -1223,7 +1254,11 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             double d2 = dot3(dl, dl);
             V3 ed = dl * fast_rsqrt(d2);
             cnt.shadow++;
+            PH_ADD(wc, PH_LIGHT, ph_t);
+            ph_t = PH_T();
             Hit sh = closest_hit_all<USE_BVH, COUNT>(sc, p, ed, h.obj, wc);
+            PH_ADD(wc, PH_SHADOW_QUERY, ph_t);
+            ph_t = PH_T();
             int lit = 0;
             if (sh.obj >= 0) {
                 const DevMat &lm = sc.mat[sh.obj];
@@ -1242,8 +1277,10 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                 }
             }
             ps.cel = clean ? 1 : lit;
+            PH_ADD(wc, PH_SHADOW_APPLY, ph_t);
         }
     } else if (dice <= diffusivity + reflectivity) {
+        ph_t = PH_T();
         if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         n = norm3(n);
@@ -1259,11 +1296,14 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                 ps.d.z += sig * random_normal(ps.rng);
             }
         }
+        PH_ADD(wc, PH_MIRROR, ph_t);
     } else if (dice <= diffusivity + reflectivity + transparency) {
+        ph_t = PH_T();
         if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         refract_ray(sc, ps, ls, p, n, h.obj, mt.r_index, cnt);
         next_os = -1;
+        PH_ADD(wc, PH_REFRACT, ph_t);
     }
     if (sc.has_refraction) {
         ls.put(LS_SRCN + 0, n.x);

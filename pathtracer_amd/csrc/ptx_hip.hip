@@ -133,6 +133,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
     int k = ks;
 #ifdef PTX_PHASE_TIMERS
     WalkCount wc_dbg = {};
+    __shared__ unsigned long long ph_lds_[3 * PTX_N_PHASES];
+    if (lane < 3 * PTX_N_PHASES) ph_lds_[lane] = 0ULL;
+    __syncthreads();
+    wc_dbg.ph = USE_BVH ? nullptr : ph_lds_;
     long long iters_dbg = 0;
     const long long t_begin_dbg = clock64();
 #endif
@@ -140,13 +144,22 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
         primary_ray(sc, rp, ls, i, j, ks, ps);
         ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
     }
+#ifdef PTX_PHASE_TIMERS
+    constexpr bool COUNT = true;  // for the PH_* macros
+    WalkCount *const wcp = &wc_dbg;
+#else
+    constexpr bool COUNT = false;
+    WalkCount *const wcp = nullptr;
+#endif
     for (;;) {
         bool ended = false;
+        long long ph_t = PH_T();
         if (!alive && k < ke) {
             if (PINHOLE) primary_ray_cached(sc, rp, ls, i, j, k, ps);
             else primary_ray(sc, rp, ls, i, j, k, ps);
             alive = true;
             ended = rp.max_depth < 1;  // reference PathTracer.c:273 with depth = 1
+            PH_ADD(wcp, PH_NEW_PATH, ph_t);
         }
         if (__ballot(alive) == 0ULL) break;
         double glossy = 0;
@@ -156,7 +169,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
 #else
         if (alive && !ended) ended = bounce<FLAGS, USE_BVH, true, false, !PINHOLE>(sc, rp, ls, ps, cnt, glossy);
 #endif
+        ph_t = PH_T();
         glossy_service(ps, glossy, lane);
+        if (__ballot(glossy > 0) != 0ULL) PH_ADD(wcp, PH_GLOSSY, ph_t);
+        ph_t = PH_T();
         if (alive && ended) {
             // Four samples make a 128-byte line of the lane's stream.  The first three wait in LDS; the fourth goes
             // out together with them, so that every line is written once and whole (sub_len and the stride are
@@ -178,9 +194,20 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
             alive = false;
             k++;
             paths++;
+            PH_ADD(wcp, PH_SAMPLE_END, ph_t);
         }
     }
 #ifdef PTX_PHASE_TIMERS
+    if (!USE_BVH) {
+        // the parts of the loop: the wave's cycles, runs and lane visits
+        __syncthreads();
+        if (lane == 0) {
+            ph_lds_[3 * PH_LOOP] = (unsigned long long)(clock64() - t_begin_dbg);
+            ph_lds_[3 * PH_LOOP + 1] = (unsigned long long)iters_dbg;
+        }
+        __syncthreads();
+        if (lane < 3 * PTX_N_PHASES && ph_lds_[lane]) atomicAdd(&stats[PTX_STATS_DBG + lane], ph_lds_[lane]);
+    }
     {
         // per-lane maxima are what the wave paid: the slowest lane's cycle counts cover the whole loops
         double v[10] = {(double)(clock64() - t_begin_dbg), (double)wc_dbg.cyc_list, (double)wc_dbg.cyc_walk, (double)iters_dbg,

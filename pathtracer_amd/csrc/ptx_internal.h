@@ -13,10 +13,11 @@
 // Device counters of a context: [0..3] paths, closest-hit queries, shadow queries, out-of-range refraction-stack
 // accesses of the render kernels since ptx_render_begin; [PTX_STATS_WALK ..] the ptx_walk_stats fields of the last
 // ptx_trace_paths call.
-// [PTX_STATS_DBG ..] cycle and lane counts of the instrumented build (-DPTX_PHASE_TIMERS) of the render kernel for
-// hierarchy scenes since the context was created, read with ptx_debug_counters() (tools/phase_timers.py).
+// [PTX_STATS_DBG ..] cycle and lane counts of the instrumented build (-DPTX_PHASE_TIMERS) since the context was created,
+// read with ptx_debug_counters() (tools/phase_timers.py): of the render kernel for hierarchy scenes (22 values), or of
+// k_trace_samples on a scene without a hierarchy (cycles, runs and lane visits of its twelve parts).
 // [PTX_STATS_WORK] the work-tile counter of the render kernel for hierarchy scenes (its low 32 bits), cleared before every launch.
-enum { PTX_STATS_WALK = 4, PTX_N_WALK = 11, PTX_STATS_DBG = PTX_STATS_WALK + PTX_N_WALK, PTX_N_DBG = 24, PTX_STATS_WORK = PTX_STATS_DBG + PTX_N_DBG,
+enum { PTX_STATS_WALK = 4, PTX_N_WALK = 11, PTX_STATS_DBG = PTX_STATS_WALK + PTX_N_WALK, PTX_N_DBG = 36, PTX_STATS_WORK = PTX_STATS_DBG + PTX_N_DBG,
        PTX_N_STATS = PTX_STATS_WORK + 1 };
 extern "C" int ptx_debug_counters(ptx_context *c, unsigned long long *out /* PTX_N_DBG values */, int clear);
 

@@ -26,7 +26,27 @@ dev.render_begin(pt.make_params(size, depth, 7, ap, seed=3))
 dev.render_passes(0, spp)
 dev.sync()
 st = dev.stats()
-if kernel == "whole" or name == "cornell":
+N_DBG = 36
+device._LIB.ptx_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+if name == "cornell":
+    # a scene without a hierarchy: the parts of k_trace_samples' loop (cycles as the waves see them, summed over the waves)
+    buf = (ctypes.c_ulonglong * N_DBG)()
+    assert device._LIB.ptx_debug_counters(dev.ctx, buf, 1) == 0
+    v = list(buf)
+    labels = ["closest-hit query", "surface (hit record, material, roulette)", "diffuse direction", "light sample", "shadow query",
+              "shadow result", "mirror", "refraction", "new path", "glossy deviates", "end of sample (store)", "whole loop"]
+    total, iters = v[3 * 11], v[3 * 11 + 1]
+    print(f"{name} {size}^2 {spp} spp: wave cycles total {total:.3e}, loop iterations {iters}, {total / iters:.0f} cycles per iteration, paths {st['paths']}")
+    acc = 0
+    for q, label in enumerate(labels[:-1]):
+        cyc, runs, lanes = v[3 * q:3 * q + 3]
+        acc += cyc
+        print(f"  {label:42s} {cyc / total:6.1%} of cycles, in {runs / iters:5.1%} of iterations, {cyc / max(runs, 1):7.0f} cycles per run, "
+              f"{lanes / max(runs, 1):5.1f} lanes per run")
+    print(f"  {'loop control and the rest':42s} {1 - acc / total:6.1%}")
+    dev.close()
+    sys.exit(0)
+if kernel == "whole":
     w = dev.last_walk_stats()
     total, lst, walk, iters = w["queries"], w["hits"], w["list_tests"], w["node_visits"]
     steps_wave, leaf_passes, nodes, queries, cyc_leaf, leaf_tests = w["leaf_tests"][:6]
@@ -36,9 +56,7 @@ if kernel == "whole" or name == "cornell":
           f"{leaf_tests / max(queries, 1):.3f} leaf tests; per wave and query phase (2 per iteration): {steps_wave / (2 * iters):.1f} walk steps "
           f"with {nodes / max(steps_wave, 1):.1f} lanes active, {leaf_passes / (2 * iters):.2f} leaf-test passes with {leaf_tests / max(leaf_passes, 1):.1f} lanes active")
 else:
-    n_dbg = 24
-    buf = (ctypes.c_ulonglong * n_dbg)()
-    device._LIB.ptx_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    buf = (ctypes.c_ulonglong * N_DBG)()
     rc = device._LIB.ptx_debug_counters(dev.ctx, buf, 1)
     assert rc == 0, rc
     (total, shade, shadow, setup, steps, leaf, regen, n_iter, n_shade, l_shade, n_shadow, l_shadow, n_setup, l_setup, n_burst, l_burst,
