@@ -61,22 +61,12 @@ __device__ __forceinline__ void fold_pixel(const double *samples, size_t pix, si
         }
         wt += (double)n_samples;
     }
-    if (q + 4 <= n_samples) {
-        // the next line is on its way while this one is folded
-        double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
-        for (; q + 8 <= n_samples; q += 4) {
-            const double4 t0 = in[q + 4], t1 = in[q + 5], t2 = in[q + 6], t3 = in[q + 7];
-            fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
-            fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
-            fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
-            fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
-            s0 = t0; s1 = t1; s2 = t2; s3 = t3;
-        }
+    for (; q + 4 <= n_samples; q += 4) {
+        const double4 s0 = in[q], s1 = in[q + 1], s2 = in[q + 2], s3 = in[q + 3];
         fold_sample(ar, ag, ab, wt, s0.x, s0.y, s0.z);
         fold_sample(ar, ag, ab, wt, s1.x, s1.y, s1.z);
         fold_sample(ar, ag, ab, wt, s2.x, s2.y, s2.z);
         fold_sample(ar, ag, ab, wt, s3.x, s3.y, s3.z);
-        q += 4;
     }
     for (; q < n_samples; q++) {
         const double4 s0 = in[q];
