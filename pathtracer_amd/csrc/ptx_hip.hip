@@ -1166,10 +1166,6 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     if (round_max < 4) return fail(PTX_EINVAL, "sample buffer too small for four passes of this image");
     const bool pinhole = c->rp.aperture == 0 && !c->rp.clean;  // every sample of a pixel starts along the same direction
     const long slots = (long)c->n_cus * 4 * (c->use_bvh ? PTX_BVH_WAVES : (!pinhole ? 3 : 4));  // waves the GPU holds at once
-    // waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and
-    // short enough runs that a slow tile does not hold the end of the launch (measured best between 16 and 32)
-    long fill = 16;
-    if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
     // Scenes with a hierarchy: the kernel that carries queries in slices (PTX_BVH_KERNEL=whole selects the kernel
     // that runs whole queries, for comparisons; the images are the same).  Its settings were swept at 2048 x 2048 on
     // SciFiCube and BubbleTea (8000 and 6300 primitives in the hierarchy: node arrays of 4 MB, served by the L2 caches,
@@ -1180,6 +1176,14 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     // better on the small scenes.
     bool sliced = true;
     if (const char *e = getenv("PTX_BVH_KERNEL")) sliced = strcmp(e, "whole") != 0;
+    // Waves wanted per slot: enough of them that the GPU stays full while waves finish at different times, and short
+    // enough runs that a slow tile does not hold the end of the launch.  k_trace_samples: 6, with the last sample range
+    // cut into four (below) -- a wave's start and its wait for its slowest pixel cost the same whatever its length, so
+    // long waves with a fine tail are best; with all ranges alike it was 16 to 32.  That matters most where a GPU holds a
+    // share of an image: rank 0's rows of an 8-rank split of the benchmark take 25.2 ms instead of 26.2 ms, the whole
+    // image 195.8 ms either way.  The kernel for hierarchy scenes hands its work tiles out itself: 16.
+    long fill = (c->use_bvh && sliced) ? 16 : 6;
+    if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
     const size_t node_bytes = (size_t)c->sc.n_bvh_nodes * sizeof(PtxBvhNode) * (c->sc.bvh_per_octant ? 8 : 1);
     const bool nodes_in_l2 = node_bytes <= ((size_t)32 << 20);  // eight L2 caches of 4 MB
     int exit_lanes = nodes_in_l2 ? 12 : 24, leaf_batch = nodes_in_l2 ? 4 : 8, shade_min = nodes_in_l2 ? 40 : 24,
@@ -1203,7 +1207,7 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
         // index, so the waves that run while the GPU empties are short and it empties almost at once (PTX_TAIL_SPLIT
         // overrides, 1: all ranges alike)
         int n_full = (int)n_sub, tail_len = sub_len;
-        long tail_split = 2;
+        long tail_split = 4;
         if (const char *e = getenv("PTX_TAIL_SPLIT")) tail_split = std::max(1L, atol(e));
         if (!(c->use_bvh && sliced) && tail_split > 1 && n_sub >= 2) {
             n_full = (int)n_sub - 1;
