@@ -176,7 +176,7 @@ def run(args):
     gat = parallel.Gatherer(sx, rank, world, band, device)  # accumulators, receive buffers and the whole image, once
     rows = gat.rows
     kernel_ms = []
-    gather_s = []
+    gather_ev = []  # pairs of events around the gathers of the timed steps, on the stream the gather runs on
 
     def step(record):
         gat.reset()
@@ -185,19 +185,24 @@ def run(args):
         while k < spp:
             nk = min(chunk, spp - k)
             dev.render_passes(k, nk)
-            if record:
-                kernel_ms.append(dev.last_trace_ms() + (nk,))
             k += nk
+            # the kernel's own time comes from the library's events around its launches; they are read (which waits
+            # for the kernel) only after the gather has been queued behind it, unless another launch is to follow
+            if record and k < spp:
+                kernel_ms.append(dev.last_trace_ms() + (nk,))
         if not shared_stream:
             dev.sync()
         if record and world > 1:
-            torch.cuda.synchronize()
-            t = time.perf_counter()
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
             out = gat.gather()
-            torch.cuda.synchronize()
-            gather_s.append(time.perf_counter() - t)
-            return out
-        return gat.gather()
+            ev[1].record()
+            gather_ev.append(ev)
+        else:
+            out = gat.gather()
+        if record:
+            kernel_ms.append(dev.last_trace_ms() + (nk,))
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -253,7 +258,7 @@ def run(args):
         },
         "mrays_per_s": paths_per_s * rays_per_path / 1e6,
         "rays_per_path": rays_per_path,
-        "gather_ms_per_step": (sum(gather_s) / len(gather_s) * 1e3) if gather_s else 0.0,
+        "gather_ms_per_step": (sum(a.elapsed_time(b) for a, b in gather_ev) / len(gather_ev)) if gather_ev else 0.0,
         "roofline": {
             "bound": "valu",
             "achieved": achieved_tflops,
