@@ -1203,13 +1203,37 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
         long n_sub = std::max(1L, std::min((fill * slots + n_tiles - 1) / n_tiles, (long)nka / 8));
         const int sub_len = (int)(((nka + n_sub - 1) / n_sub + 3) & ~3L);
         n_sub = (nka + sub_len - 1) / sub_len;
-        // k_trace_samples: the last of these ranges is cut into tail_split shorter ones.  Blocks start in the order of their
-        // index, so the waves that run while the GPU empties are short and it empties almost at once (PTX_TAIL_SPLIT
-        // overrides, 1: all ranges alike)
+        // k_trace_samples cuts the samples differently.  The lanes of a wave wait for the one whose paths were longest, and
+        // what they wait is the spread of a sum of path lengths, which grows with the root of the number of samples: 8 % of
+        // a wave of 125 samples, 4 % of one of 500 (measured: 60 of 64 lanes alive with [500, 125 x 4]).  So the waves
+        // should be as long as possible -- but blocks start in the order of their index, and the GPU empties as slowly as
+        // its last waves are long.  Hence a head of long ranges, as many as fill the GPU head_rounds times, over
+        // head_permille of the samples, and the rest in tail_split short ranges that level the end of the launch.  Swept on
+        // the benchmark (1024^2, 1000 samples) and on one GPU's share of a 2-, 4- and 8-GPU split: 4 rounds, 875, 4 pieces
+        // (800 to 920 within 0.5 %; beyond 930 the tail no longer covers the spread of the last long waves).
+        // PTX_HEAD_PERMILLE=0: ranges of equal length with the last one in tail_split pieces; PTX_TAIL_SPLIT=1: all alike.
         int n_full = (int)n_sub, tail_len = sub_len;
         long tail_split = 4;
         if (const char *e = getenv("PTX_TAIL_SPLIT")) tail_split = std::max(1L, atol(e));
-        if (!(c->use_bvh && sliced) && tail_split > 1 && n_sub >= 2) {
+        int sub_len_k = sub_len;
+        long head_permille = 875, head_rounds = 4;
+        if (const char *e = getenv("PTX_HEAD_PERMILLE")) head_permille = std::max(0L, std::min(990L, atol(e)));
+        if (const char *e = getenv("PTX_HEAD_ROUNDS")) head_rounds = std::max(1L, atol(e));
+        const long n_head = std::max(1L, (head_rounds * slots + n_tiles - 1) / n_tiles);
+        const long head_len = ((nka * head_permille / 1000 + n_head - 1) / n_head + 3) & ~3L;
+        // (not where the head's ranges would be shorter than 32 samples: few samples on a small image)
+        if (!(c->use_bvh && sliced) && head_permille > 0 && tail_split > 1 && head_len >= 32) {
+            sub_len_k = (int)head_len;
+            n_full = (int)std::min(n_head, (long)nka / sub_len_k);
+            const long rest = nka - (long)n_full * sub_len_k;
+            if (rest > 0) {
+                tail_len = (int)(((rest + tail_split - 1) / tail_split + 3) & ~3L);
+                n_sub = n_full + (rest + tail_len - 1) / tail_len;
+            } else {
+                tail_len = sub_len_k;
+                n_sub = n_full;
+            }
+        } else if (!(c->use_bvh && sliced) && tail_split > 1 && n_sub >= 2) {
             n_full = (int)n_sub - 1;
             const long rest = nka - (long)n_full * sub_len;
             tail_len = (int)(((rest + tail_split - 1) / tail_split + 3) & ~3L);
@@ -1243,10 +1267,10 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
                                        exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
             } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
+                                   sub_len_k, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
             else
                 hipLaunchKernelGGL((k_trace_samples<F, B, false>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                   sub_len, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
+                                   sub_len_k, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);
         });
         HIPCHK(hipGetLastError());
         if (per_launch_timing) {

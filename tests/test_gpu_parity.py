@@ -548,6 +548,24 @@ def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
     assert got[1][3] == 10 and got[0][3] == 1  # launches of the tracing kernel: ten rounds of four samples, one round
     for rgb, w, st, _ in got[1:]:
         assert np.array_equal(rgb, got[0][0]) and np.array_equal(w, got[0][1]) and st == got[0][2]
+    # where there are enough samples for them, a head of long ranges and a tail of short ones: whatever their proportions
+    sx, spp = 512, 100
+    prm = pt.make_params(sx, 6, ALL, 0.0, seed=12)
+    got = []
+    for head, rounds, tail_split, buffer_mb in ((None, None, None, None), ("0", None, None, None), ("0", None, "1", None), ("500", "1", "3", None),
+                                                ("875", "2", None, None), ("990", "1", "9", None), ("875", "1", None, "704")):
+        for var, val in (("PTX_HEAD_PERMILLE", head), ("PTX_HEAD_ROUNDS", rounds), ("PTX_TAIL_SPLIT", tail_split),
+                         ("PTX_SAMPLE_BUFFER_MB", buffer_mb)):  # 704 MiB: 88 samples of 512 x 512 pixels, then 12
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
+        dev.render_begin(prm)
+        dev.render_passes(0, spp)
+        rgb, w = dev.download()
+        got.append((rgb, w, dev.stats()))
+    for rgb, w, st in got[1:]:
+        assert np.array_equal(rgb, got[0][0]) and np.array_equal(w, got[0][1]) and st == got[0][2]
 
 
 def test_render_resumed_from_saved_accumulators(gpu):
