@@ -1227,7 +1227,8 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
             n_full = (int)std::min(n_head, (long)nka / sub_len_k);
             const long rest = nka - (long)n_full * sub_len_k;
             if (rest > 0) {
-                tail_len = (int)(((rest + tail_split - 1) / tail_split + 3) & ~3L);
+                const long pieces = std::max(1L, std::min(tail_split, rest / 8));  // none shorter than 8 samples
+                tail_len = (int)(((rest + pieces - 1) / pieces + 3) & ~3L);
                 n_sub = n_full + (rest + tail_len - 1) / tail_len;
             } else {
                 tail_len = sub_len_k;
@@ -1236,7 +1237,8 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
         } else if (!(c->use_bvh && sliced) && tail_split > 1 && n_sub >= 2) {
             n_full = (int)n_sub - 1;
             const long rest = nka - (long)n_full * sub_len;
-            tail_len = (int)(((rest + tail_split - 1) / tail_split + 3) & ~3L);
+            const long pieces = std::max(1L, std::min(tail_split, rest / 8));  // none shorter than 8 samples: a wave's start
+            tail_len = (int)(((rest + pieces - 1) / pieces + 3) & ~3L);       // costs as much as a few samples
             n_sub = n_full + (rest + tail_len - 1) / tail_len;
         }
         if (n_tiles * n_sub > 0x7fffffffL) return fail(PTX_EINVAL, "ptx_render_passes: image too large for one launch");
