@@ -566,6 +566,20 @@ def test_rounds_and_wave_sizes_do_not_change_results(gpu, monkeypatch):
         got.append((rgb, w, dev.stats()))
     for rgb, w, st in got[1:]:
         assert np.array_equal(rgb, got[0][0]) and np.array_equal(w, got[0][1]) and st == got[0][2]
+    # sample counts that leave the tail little or nothing
+    monkeypatch.delenv("PTX_SAMPLE_BUFFER_MB", raising=False)
+    monkeypatch.delenv("PTX_TAIL_SPLIT", raising=False)
+    monkeypatch.setenv("PTX_HEAD_ROUNDS", "1")
+    for spp in (33, 36, 41, 68):
+        got = []
+        for head in ("0", "875", "990"):
+            monkeypatch.setenv("PTX_HEAD_PERMILLE", head)
+            dev.render_begin(prm)
+            dev.render_passes(0, spp)
+            rgb, w = dev.download()
+            got.append((rgb, w, dev.stats()))
+        for rgb, w, st in got[1:]:
+            assert np.array_equal(rgb, got[0][0]) and np.array_equal(w, got[0][1]) and st == got[0][2]
 
 
 def test_render_resumed_from_saved_accumulators(gpu):
