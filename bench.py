@@ -40,13 +40,25 @@ def recorded_hbm_traffic(rows, sx):
             # FP64 operations executed per launch, as the counters saw them: (2 FMA + ADD + MUL wave-instructions) x the
             # average number of active lanes per vector instruction
             flop = rec.get("f64_flop_counted", 0) * rec.get("active_lanes_per_valu_inst", 0) / max(1, rec.get("launches_per_run", 1))
-            best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path), flop)
+            best = (rec["hbm_bytes_per_launch"]["total"], os.path.basename(path), flop, rec.get("library_sha16"))
         except (OSError, ValueError, KeyError):
             continue
     if best is None:
-        return None, None, None
+        return None, None, None, None
     share = (rows * sx) / float(1024 * 1024)
-    return best[0] * share, best[1], best[2] * share
+    return best[0] * share, best[1], best[2] * share, best[3]
+
+
+def library_stamp():
+    """First 16 hex digits of the SHA-256 of the kernel library this run loads (tools/pmc_summary.py stamps the counter
+    summaries the same way)."""
+    import hashlib
+
+    try:
+        with open(os.path.join(REPO, "pathtracer_amd", "lib", "libptx_hip.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def cpu_baseline(sx, depth, flags, seconds_target=15.0):
@@ -126,7 +138,9 @@ def main():
     if args.gpus > 1 and not launch.under_launcher():
         # plain `python bench.py --gpus N`: this process starts the N ranks (it has not touched the GPU) and hands on
         # rank 0's line.  Under torch.distributed.run the ranks exist already.
-        rc, out = launch.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        # (bounded: a rank that hangs must not hold the GPUs; PTX_BENCH_TIMEOUT seconds, default 25 minutes)
+        rc, out = launch.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                      timeout=float(os.environ.get("PTX_BENCH_TIMEOUT", "1500")))
         sys.stdout.write(out)
         sys.stdout.flush()
         sys.exit(rc)
@@ -180,6 +194,9 @@ def run(args):
 
     def step(record):
         gat.reset()
+        if not shared_stream:
+            # the reset is queued on PyTorch's stream, the render on the library's own: order them on the host
+            torch.cuda.current_stream().synchronize()
         dev.render_begin(prm, gat.rgb_local.data_ptr(), gat.wght_local.data_ptr())
         k = 0
         while k < spp:
@@ -234,7 +251,17 @@ def run(args):
     achieved_tflops = paths_launches * FLOP_PER_PATH / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0
     rays_per_path = (stats["closest_hits"] + stats["shadow_rays"]) / max(1, stats["paths"])
     same_workload = sx == 1024 and spp == 1000 and chunk == spp and depth == 6
-    traffic, traffic_src, counted_flop = recorded_hbm_traffic(rows, sx) if same_workload else (None, None, None)
+    traffic, traffic_src, counted_flop, traffic_lib = recorded_hbm_traffic(rows, sx) if same_workload else (None, None, None, None)
+    lib_stamp = library_stamp()
+    # every rank's share and kernel time, so that an uneven split or a slow GPU shows in the line
+    mine = torch.tensor([float(rows), ms_sum / max(1, args.steps)], dtype=torch.float64, device="cpu" if args.rehearse else device)
+    if world > 1:
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+    else:
+        every = [mine]
+    rows_per_rank = [int(t[0].item()) for t in every]
+    per_rank_kernel_ms = [float(t[1].item()) for t in every]
     executed_tflops = counted_flop / (ms_sum / max(1, n_launches) * 1e-3) / 1e12 if counted_flop and ms_sum > 0 else None
     out = {
         "metric": "paths/s (pixel-samples per second), Cornell box 1024^2 depth 6 IS+ES+RR",
@@ -259,6 +286,9 @@ def run(args):
         "mrays_per_s": paths_per_s * rays_per_path / 1e6,
         "rays_per_path": rays_per_path,
         "gather_ms_per_step": (sum(a.elapsed_time(b) for a, b in gather_ev) / len(gather_ev)) if gather_ev else 0.0,
+        "rows_per_rank": rows_per_rank,
+        "per_rank_kernel_ms": {"per_step": per_rank_kernel_ms, "min": min(per_rank_kernel_ms), "max": max(per_rank_kernel_ms)},
+        "library_sha16": lib_stamp,
         "roofline": {
             "bound": "valu",
             "achieved": achieved_tflops,
@@ -270,6 +300,8 @@ def run(args):
             "executed_frac_of_fp64_vector_peak": None if executed_tflops is None else executed_tflops / PEAK_FP64_TFLOPS,
             "traffic": traffic,
             "traffic_source": None if traffic_src is None else f"recorded: profiles/{traffic_src} (same workload, counters of an earlier run)",
+            "traffic_profile_library_sha16": traffic_lib,
+            "traffic_profile_is_of_this_build": None if traffic_src is None else (traffic_lib is not None and traffic_lib == lib_stamp),
             "algorithmic_hbm_bytes_per_launch": 32 * paths_launches // max(1, n_launches),
             "kernel": "k_trace_samples",
             "kernel_ms_avg": ms_sum / max(1, n_launches),

@@ -701,6 +701,7 @@ struct ptx_context {
     // whole-image buffers of ptx_gather (on the context that receives the rows), grown on demand
     double *d_whole_rgb = nullptr, *d_whole_wght = nullptr;
     size_t whole_pixels = 0;
+    ptx_tonemap_scratch tonemap;  // scratch of ptx_tonemap / ptx_tonemap_device, allocated at the first image
 };
 
 static void free_scene(ptx_context *c) {
@@ -762,6 +763,7 @@ extern "C" void ptx_shutdown(ptx_context *c) {
     (void)hipFree(c->d_samples);
     (void)hipFree(c->d_whole_rgb);
     (void)hipFree(c->d_whole_wght);
+    ptx_tonemap_release(c->tonemap);
     for (hipEvent_t e : c->trace_ev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1196,7 +1198,9 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     int lds_nodes = 0;
     if (const char *e = getenv("PTX_WALK_LDS_NODES")) lds_nodes = std::max(0, std::min(PTX_LDS_TOP_MAX, atoi(e)));
     c->n_trace_launches = 0;
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    // (no events on the path that must stay capturable into a HIP graph: the timing getters then report PTX_ESTATE)
+    c->have_timing = false;
+    if (per_launch_timing) HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int ka = k0; ka < k0 + nk; ka += round_max) {
         const int nka = std::min(round_max, k0 + nk - ka);
         // a wave traces sub_len samples of a tile: as long a run as leaves enough waves, and at least 8
@@ -1283,8 +1287,10 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
                            c->d_rgb, c->d_wght, c->rp.clean);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
-    c->have_timing = true;
+    if (per_launch_timing) {
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        c->have_timing = true;
+    }
     return PTX_OK;
 }
 
@@ -1297,7 +1303,11 @@ extern "C" int ptx_render_passes(ptx_context *c, int k0, int nk) {
     const size_t n_pix = (size_t)c->rp.rows_owned * c->rp.sx;
     const size_t bytes_per_pass = n_pix * PTX_SAMPLE_DOUBLES * sizeof(double);
     const size_t cap = sample_buffer_cap(c->samples_bytes);
-    const size_t round_max = std::max<size_t>(4, std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (cap / bytes_per_pass) & ~(size_t)3));
+    const size_t round_max = std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (cap / bytes_per_pass) & ~(size_t)3);
+    if (round_max < 4)
+        return fail(PTX_ENOMEM, "ptx_render_passes: the sample buffer cap (PTX_SAMPLE_BUFFER_MB, or half the free device memory) cannot "
+                                "hold four passes of this rank's " + std::to_string(n_pix) + " pixels (" +
+                                std::to_string(4 * bytes_per_pass >> 20) + " MiB needed)");
     if (round_max * bytes_per_pass > c->samples_bytes) {
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_samples);
@@ -1359,7 +1369,7 @@ extern "C" int ptx_tonemap_device(ptx_context *c, const double *d_im, uint64_t n
     if (n_values == 0) return fail(PTX_EINVAL, "ptx_tonemap_device: empty image");
     HIPCHK(hipSetDevice(c->device));
     std::string err;
-    int rc = ptx_tonemap_run(c->stream, d_im, (size_t)n_values, bits, info, err);
+    int rc = ptx_tonemap_run(c->stream, c->tonemap, d_im, (size_t)n_values, bits, info, err);
     return rc ? fail(rc, err) : PTX_OK;
 }
 

@@ -21,8 +21,20 @@ enum { PTX_STATS_WALK = 4, PTX_N_WALK = 11, PTX_STATS_DBG = PTX_STATS_WALK + PTX
        PTX_N_STATS = PTX_STATS_WORK + 1 };
 extern "C" int ptx_debug_counters(ptx_context *c, unsigned long long *out /* PTX_N_DBG values */, int clear);
 
+// Scratch buffers of the tone mapping, owned by a context: allocated at the first image (the byte image again when a
+// larger one is asked for), released with the context.
+struct ptx_tonemap_scratch {
+    double *d_part = nullptr;              // block minima and maxima
+    double *d_prm = nullptr;               // min, max, range, low cut, high cut, cut range
+    unsigned long long *d_hist = nullptr;  // 1000 bins
+    unsigned long long *d_unsure = nullptr;
+    uint8_t *d_bits = nullptr;
+    size_t bits_bytes = 0;
+};
 // Tone-maps n accumulator values on the device (d_im) into n bytes on the host; returns a PTX_* code and, on
 // failure, a message in err.  Defined in ptx_tonemap.hip.
-int ptx_tonemap_run(hipStream_t stream, const double *d_im, size_t n, uint8_t *h_bits, ptx_tonemap_info *info, std::string &err);
+int ptx_tonemap_run(hipStream_t stream, ptx_tonemap_scratch &ws, const double *d_im, size_t n, uint8_t *h_bits, ptx_tonemap_info *info,
+                    std::string &err);
+void ptx_tonemap_release(ptx_tonemap_scratch &ws);
 
 #endif

@@ -1,4 +1,7 @@
 """Comparison rules shared by the CPU and GPU parity tests."""
+import json
+import os
+
 import numpy as np
 
 from pathtracer_amd import abi
@@ -8,6 +11,43 @@ FIRST_HIT_RTOL = 1e-5
 
 
 TIE_RTOL = 1e-9
+
+# What the parity tests measured, kept beside their verdicts: with PTX_PARITY_JSON=<file> in the environment every
+# record() call adds one entry to that file (a JSON object keyed by entry name, rewritten after each call so that a
+# run that stops early still leaves what it had).  Off by default.
+_RECORDS = {}
+
+
+def record(name, **fields):
+    path = os.environ.get("PTX_PARITY_JSON")
+    if not path:
+        return
+    clean = {}
+    for k, v in fields.items():
+        if isinstance(v, (np.floating, np.integer)):
+            v = v.item()
+        elif isinstance(v, np.ndarray):
+            v = v.tolist()
+        clean[k] = v
+    _RECORDS[name] = clean
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(_RECORDS, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+def unbiased_mismatches(got, want, atol=1e-9, rtol=1e-7, sigmas=6.0):
+    """Paths that differ from the other side's do so because rounding flipped a discrete choice somewhere, which
+    sends them to another, equally probable continuation: their differences must scatter around zero.  True when
+    the sum of the differences over the differing paths is within `sigmas` standard deviations of zero (a
+    systematic error -- always darker, a missing term -- fails this as soon as a few dozen paths differ)."""
+    d = (got - want).reshape(len(got), -1)
+    bad = np.abs(d).max(axis=1) > atol + rtol * np.abs(want.reshape(len(want), -1)).max(axis=1)
+    if bad.sum() < 8:
+        return True
+    tot = d[bad].sum(axis=0)
+    sd = np.sqrt((d[bad] ** 2).sum(axis=0))
+    return bool(np.all(np.abs(tot) <= sigmas * sd + 1e-12))
 
 
 def prove_ties(rays, got, want, requery):
@@ -124,7 +164,10 @@ def compare_hits(got, want, scene, rtol=FIRST_HIT_RTOL, exact=False, rays=None, 
             msg += "".join(f", {reasons.count(k)} {k}" for k in ("slab", "surface") if k in reasons)
             unproven = np.asarray([r for r, why in zip(unproven, reasons) if why is None], dtype=np.int64)
         print(msg)
+        record("first_hit/" + label, rays=len(got), ids_differ=int(id_bad.sum()), unproven=int(len(unproven)), note=msg)
         assert len(unproven) == 0, f"object ids differ without a tie on rays {unproven[:8]}"
+    elif label:
+        record("first_hit/" + label, rays=len(got), ids_differ=0, unproven=0)
     m = (want["obj"] >= 0) & ~id_bad
     types = scene.objects["type"][want["obj"][m]]
     uv_defined = (types != abi.TRIANGLE) & (types != abi.ROOM)

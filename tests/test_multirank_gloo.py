@@ -96,6 +96,35 @@ def test_a_failing_rank_fails_the_launch(tmp_path):
     assert rc == 3
 
 
+@pytest.mark.parametrize("world,bad", [(2, 1), (3, 2), (2, 0)])
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_launch_at_once(world, bad, tmp_path):
+    """Rank `bad` exits with code 3 before init_process_group; the others are by then waiting for it at the
+    rendezvous.  The launch must end them and return that code within seconds, not after the store's timeout."""
+    import time
+
+    from pathtracer_amd import launch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GLOO_SOCKET_IFNAME"] = env.get("GLOO_SOCKET_IFNAME", "lo")
+    t0 = time.monotonic()
+    rc, _ = launch.launch_ranks([sys.executable, os.path.join(REPO, "tests", "multirank_child.py"), str(tmp_path / "x.npz"), str(bad)],
+                                world, env=env, timeout=240)
+    dt = time.monotonic() - t0
+    assert rc == 3
+    assert dt < 60, f"the launch took {dt:.0f} s to notice the dead rank"
+
+
+def test_a_launch_that_runs_out_of_time_is_ended(tmp_path):
+    import time
+
+    from pathtracer_amd import launch
+
+    t0 = time.monotonic()
+    rc, out = launch.launch_ranks([sys.executable, "-c", "import time; print('started', flush=True); time.sleep(600)"], 2, timeout=3)
+    assert rc == 124 and time.monotonic() - t0 < 30
+    assert "started" in out  # what rank 0 had printed is still handed on
+
+
 def test_band_height_shrinks_for_small_images():
     from pathtracer_amd import parallel
 

@@ -55,3 +55,41 @@ def test_static_sample_buffer_rejects_images_beyond_its_size(gpu):
     assert lib.ptx_render_passes_static(dev.ctx, 0, 4) == 0
     dev.sync()
     assert dev.stats()["paths"] == 2048 * 1024 * 4
+
+
+def test_static_entry_point_captured_into_a_graph_and_replayed(gpu):
+    """What the entry point is for: a caller under HIP graph capture.  The call is captured on a PyTorch stream (the
+    library launches on the stream it is given), nothing runs during the capture, and two replays continue the
+    render as two direct calls do.  The timing getters have nothing to report after such a call."""
+    import torch
+
+    from pathtracer_amd import parallel
+
+    if len(parallel.hip_runtime_copies()) != 1:
+        pytest.skip("the library and PyTorch use two copies of the HIP runtime: a PyTorch stream means nothing to the library")
+    dev = gpu["cornell"]
+    prm = pt.make_params(256, 6, ALL, 0.0, seed=77)
+    dev.render_begin(prm)
+    dev.render_passes_static(0, 8)
+    dev.render_passes_static(0, 8)
+    want_rgb, want_w = dev.download()
+    import ctypes
+
+    assert dev.lib.ptx_last_pass_ms(dev.ctx, ctypes.byref(ctypes.c_float())) == -3  # PTX_ESTATE
+
+    stream = torch.cuda.Stream()
+    try:
+        dev.set_stream(stream.cuda_stream)
+        dev.render_begin(prm)
+        dev.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            dev.render_passes_static(0, 8)
+        assert dev.stats()["paths"] == 0  # captured, not run
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        got_rgb, got_w = dev.download()
+    finally:
+        dev.set_stream(None)
+    assert np.array_equal(got_rgb, want_rgb) and np.array_equal(got_w, want_w)

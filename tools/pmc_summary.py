@@ -9,21 +9,42 @@ spilled registers; its writes are the traced samples (24 bytes per path) and spi
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
+import re
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def library_stamp():
+    """First 16 hex digits of the SHA-256 of the library the profiled process loaded: bench.py prints the same stamp of
+    the library it runs, so a counter summary taken with another build of the kernels is recognisable as stale."""
+    try:
+        with open(os.path.join(REPO, "pathtracer_amd", "lib", "libptx_hip.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
 
 d = sys.argv[1]
 tot = collections.defaultdict(float)
 launches = collections.defaultdict(int)
+names = collections.Counter()
 for f in glob.glob(f"{d}/p*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         if "k_trace_samples" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             seen.add(r["Dispatch_Id"])
+            names[re.sub(r"^void |\(.*$", "", r["Kernel_Name"])] += 1
     for c in {r["Counter_Name"] for r in csv.DictReader(open(f)) if "k_trace_samples" in r["Kernel_Name"]}:
         launches[c] = max(launches[c], len(seen))
-out = {"kernel": "k_trace_samples", "workload": sys.argv[2] if len(sys.argv) > 2 else "bench", "launches_per_run": max(launches.values()) if launches else 0,
+# "kernel": the family the counters were filtered by (what bench.py looks for); "kernel_names": the instantiations seen
+family = "k_trace_samples_bvh" if names and all(n.startswith("k_trace_samples_bvh") for n in names) else "k_trace_samples"
+out = {"kernel": family, "kernel_names": sorted(names), "workload": sys.argv[2] if len(sys.argv) > 2 else "bench",
+       "library_sha16": library_stamp(), "launches_per_run": max(launches.values()) if launches else 0,
        "counters": {k: tot[k] for k in sorted(tot)}}
 n = max(1, out["launches_per_run"])
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
