@@ -28,12 +28,37 @@ struct PtxBvhNode {
 #define PTX_LEAF_TYPE_SHIFT 28
 static_assert(sizeof(PtxBvhNode) == 32, "PtxBvhNode layout");
 
+// The same hierarchy four children to a node, for scenes whose node arrays are far larger than the L2 caches: there a
+// step of the walk waits for device memory, and what it waits for is a whole 128-byte line whatever it uses of it.  A
+// wide node is one such line: the boxes of the four grandchildren of a node of the binary tree (of a child itself where
+// that child is a leaf: its second slot is then empty) and what lies below each.  The walk keeps the children it has
+// yet to visit on a short stack per lane, so one array serves all ray directions; half as many dependent fetches per
+// ray as the binary walk, every fetched byte used.
+struct PtxWideNode {
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];  // child boxes, rounded outward like PtxBvhNode::box; an empty
+                                                                // slot has lo = +infinity, hi = -infinity (never entered)
+    int32_t child[4];  // >= 0: a leaf, the caller's value for the primitive (PTX_LEAF_*); < 0: ~index of a wide node
+    uint8_t order[8];  // per octant of ray directions: the four slots, two bits each from bit 0, in the order in which a
+                       // ray of that octant should visit them (nearer first, by the split axes of the binary nodes)
+    int32_t pad[2];
+};
+static_assert(sizeof(PtxWideNode) == 128, "PtxWideNode layout");
+
+struct PtxBvhBuilt {
+    PtxBvhNode *d_nodes = nullptr;  // n_orders arrays of n_nodes = 2n-1 nodes each, back to back (caller frees with hipFree)
+    int n_nodes = 0;
+    float coord_bound = 0;          // no bound of any node exceeds this in magnitude
+    PtxWideNode *d_wide = nullptr;  // n_wide wide nodes, the root first (caller frees), or null
+    int n_wide = 0;
+    int wide_depth = 0;             // wide nodes on the longest path from the root to a primitive
+};
+
 // Builds the hierarchy over n primitives given their world boxes (host memory, 6 doubles each) and the scene
 // leaf value of each (non-negative).  n_orders is 1 (one array, left child first) or 8 (one array per octant of ray directions,
-// octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, nearer child first).  On success *d_nodes_out points to
-// n_orders arrays of *n_nodes_out = 2n-1 nodes each, back to back in device memory (caller frees with hipFree);
+// octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, nearer child first).  On success out->d_nodes points to
+// n_orders arrays of out->n_nodes = 2n-1 nodes each, back to back in device memory;
 // links are relative to the start of their own array.
 // use_sah: topology by the surface-area heuristic, built on the host, instead of the Morton-code build on the GPU.
-// *coord_bound (if not null): no bound of any node exceeds it in magnitude.
-int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
-                  PtxBvhNode **d_nodes_out, int *n_nodes_out, float *coord_bound, std::string &err);
+// want_wide: also emit the four-wide form of the same tree (PtxWideNode).
+int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, bool want_wide, hipStream_t stream,
+                  PtxBvhBuilt *out, std::string &err);

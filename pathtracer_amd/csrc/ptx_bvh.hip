@@ -209,6 +209,79 @@ __global__ void k_emit(const double *__restrict__ boxes, const int *__restrict__
     out[pre] = node;
 }
 
+// ---- the same tree, four children to a node (PtxWideNode)
+// Depth of every inner node of the binary tree (the root has depth 0), and the largest depth of any leaf.
+__global__ void k_depth(int n, const int *__restrict__ parent_inner, const int *__restrict__ parent_leaf, int *__restrict__ depth,
+                        int *__restrict__ even_flag, int *__restrict__ max_leaf_depth) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n - 1) return;
+    if (t < n - 1) {
+        int d = 0;
+        for (int p = parent_inner[t]; p >= 0; p = parent_inner[p]) d++;
+        depth[t] = d;
+        even_flag[t] = (d & 1) == 0;
+    } else {
+        int d = 0;
+        for (int p = parent_leaf[t - (n - 1)]; p >= 0; p = parent_inner[p]) d++;
+        atomicMax(max_leaf_depth, d);
+    }
+}
+
+// One wide node per inner node of even depth: the four grandchildren (or a child itself where it is a leaf) with their
+// boxes, and for each octant of ray directions the order in which to visit them -- the nearer child of the node first
+// and, within each child, its nearer child first (k_order's choice for the three binary nodes involved).
+__global__ void k_emit_wide(const double *__restrict__ boxes, const int *__restrict__ ids, const int *__restrict__ prim_ids, int n,
+                            double margin, const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ depth,
+                            const int *__restrict__ wide_index, const unsigned char *__restrict__ order,
+                            const double *__restrict__ inner_box, PtxWideNode *__restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    PtxWideNode w;
+    for (int s = 0; s < 4; s++) {
+        w.lo_x[s] = w.lo_y[s] = w.lo_z[s] = INFINITY;
+        w.hi_x[s] = w.hi_y[s] = w.hi_z[s] = -INFINITY;
+        w.child[s] = 0;
+    }
+    w.pad[0] = w.pad[1] = 0;
+    auto put = [&](int slot, int child) {  // child: >= 0 inner node (of even depth), < 0 leaf ~sorted position
+        const double *b = child >= 0 ? inner_box + 6 * (size_t)child : boxes + 6 * (size_t)ids[~child];
+        w.lo_x[slot] = outward(b[0], 0, margin); w.hi_x[slot] = outward(b[1], 1, margin);
+        w.lo_y[slot] = outward(b[2], 0, margin); w.hi_y[slot] = outward(b[3], 1, margin);
+        w.lo_z[slot] = outward(b[4], 0, margin); w.hi_z[slot] = outward(b[5], 1, margin);
+        w.child[slot] = child >= 0 ? ~wide_index[child] : prim_ids[ids[~child]];
+    };
+    if (n == 1) {  // a lone primitive: no inner node at all
+        if (t != 0) return;
+        put(0, ~0);
+        for (int o = 0; o < 8; o++) w.order[o] = 0xE4;  // slots 0, 1, 2, 3
+        out[0] = w;
+        return;
+    }
+    if (t >= n - 1 || (depth[t] & 1)) return;
+    const int side[2] = {left[t], right[t]};
+    for (int h = 0; h < 2; h++) {
+        const int c = side[h];
+        if (c < 0) {
+            put(2 * h, c);
+        } else {
+            put(2 * h, left[c]);
+            put(2 * h + 1, right[c]);
+        }
+    }
+    for (int o = 0; o < 8; o++) {
+        const int first_half = (order[t] >> o) & 1;  // 1: the right child's pair comes first
+        unsigned bits = 0;
+        for (int q = 0; q < 2; q++) {
+            const int h = q ^ first_half;
+            const int c = side[h];
+            const int swap = c >= 0 ? (order[c] >> o) & 1 : 0;
+            bits |= (unsigned)(2 * h + swap) << (4 * q);
+            bits |= (unsigned)(2 * h + (swap ^ 1)) << (4 * q + 2);
+        }
+        w.order[o] = (unsigned char)bits;
+    }
+    out[wide_index[t]] = w;
+}
+
 // Topology by the surface-area heuristic, on the host: the same arrays k_hierarchy fills (a permutation of the
 // primitives in which every inner node covers a run first..last, its two children, the parents), so that refit,
 // child order and emission are shared with the Morton build.  Top-down; every node is split where
@@ -362,10 +435,9 @@ void build_sah(const double *boxes, int n, SahTopology &t) {
 
 }  // namespace
 
-int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, hipStream_t stream,
-                  PtxBvhNode **d_nodes_out, int *n_nodes_out, float *coord_bound, std::string &err) {
-    *d_nodes_out = nullptr;
-    *n_nodes_out = 0;
+int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_orders, bool use_sah, bool want_wide, hipStream_t stream,
+                  PtxBvhBuilt *out, std::string &err) {
+    *out = PtxBvhBuilt();
     if (n <= 0) return 0;
     if (n_orders != 1 && n_orders != 8) {
         err = "ptx_bvh_build: one order or eight";
@@ -394,9 +466,12 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
         *d_pleaf = nullptr, *d_first = nullptr, *d_last = nullptr, *d_arrived = nullptr;
     unsigned long long *d_codes = nullptr, *d_codes2 = nullptr;
     unsigned char *d_order = nullptr;
-    void *d_tmp = nullptr;
+    void *d_tmp = nullptr, *d_scan_tmp = nullptr;
     PtxBvhNode *d_nodes = nullptr;
-    size_t tmp_bytes = 0;
+    PtxWideNode *d_wide = nullptr;
+    int *d_depth = nullptr, *d_even = nullptr, *d_widx = nullptr, *d_maxdepth = nullptr;
+    int n_wide = 0, wide_depth = 0;
+    size_t tmp_bytes = 0, scan_bytes = 0;
     const int n_inner = n > 1 ? n - 1 : 1;
     const unsigned gb = (unsigned)((n + 255) / 256), gb2 = (unsigned)((2 * n - 1 + 255) / 256);
     int rc = -1;
@@ -450,7 +525,7 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
                            d_arrived);
         BVHCHK(hipGetLastError());
     }
-    if (n > 1 && n_orders == 8) {
+    if (n > 1 && (n_orders == 8 || want_wide)) {
         hipLaunchKernelGGL(k_order, dim3(gb), dim3(256), 0, stream, d_boxes, d_ids2, n, d_left, d_right, d_inner_box, d_order);
         BVHCHK(hipGetLastError());
     }
@@ -459,16 +534,54 @@ int ptx_bvh_build(const double *h_boxes, const int *h_prim_ids, int n, int n_ord
                            d_first, d_last, d_order, d_inner_box, d_nodes + (size_t)o * (2 * n - 1));
         BVHCHK(hipGetLastError());
     }
+    if (want_wide) {
+        // wide nodes: the inner nodes of even depth, numbered in index order (the root, inner node 0, first)
+        int max_leaf_depth = 0;
+        BVHCHK(hipMalloc((void **)&d_depth, sizeof(int) * (size_t)n_inner));
+        BVHCHK(hipMalloc((void **)&d_even, sizeof(int) * (size_t)n_inner));
+        BVHCHK(hipMalloc((void **)&d_widx, sizeof(int) * (size_t)n_inner));
+        BVHCHK(hipMalloc((void **)&d_maxdepth, sizeof(int)));
+        BVHCHK(hipMemsetAsync(d_maxdepth, 0, sizeof(int), stream));
+        BVHCHK(hipMemsetAsync(d_even, 0, sizeof(int) * (size_t)n_inner, stream));
+        if (n > 1) {
+            hipLaunchKernelGGL(k_depth, dim3(gb2), dim3(256), 0, stream, n, d_pin, d_pleaf, d_depth, d_even, d_maxdepth);
+            BVHCHK(hipGetLastError());
+            BVHCHK(rocprim::exclusive_scan(nullptr, scan_bytes, d_even, d_widx, 0, (size_t)n_inner, rocprim::plus<int>(), stream));
+            BVHCHK(hipMalloc(&d_scan_tmp, scan_bytes ? scan_bytes : 16));
+            BVHCHK(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_even, d_widx, 0, (size_t)n_inner, rocprim::plus<int>(), stream));
+            int last_idx = 0, last_flag = 0;
+            BVHCHK(hipMemcpyAsync(&last_idx, d_widx + (n_inner - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            BVHCHK(hipMemcpyAsync(&last_flag, d_even + (n_inner - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            BVHCHK(hipMemcpyAsync(&max_leaf_depth, d_maxdepth, sizeof(int), hipMemcpyDeviceToHost, stream));
+            BVHCHK(hipStreamSynchronize(stream));
+            n_wide = last_idx + last_flag;
+        } else {
+            n_wide = 1;
+            max_leaf_depth = 1;
+        }
+        // a leaf at depth d of the binary tree (the root's children have depth 1) is a child of the wide node made from
+        // its ancestor of depth d-1 or d-2, whichever is even
+        wide_depth = (max_leaf_depth - 1) / 2 + 1;
+        BVHCHK(hipMalloc((void **)&d_wide, sizeof(PtxWideNode) * (size_t)n_wide));
+        hipLaunchKernelGGL(k_emit_wide, dim3(gb), dim3(256), 0, stream, d_boxes, d_ids2, d_prim, n, margin, d_left, d_right, d_depth, d_widx,
+                           d_order, d_inner_box, d_wide);
+        BVHCHK(hipGetLastError());
+    }
     BVHCHK(hipStreamSynchronize(stream));
-    *d_nodes_out = d_nodes;
-    *n_nodes_out = 2 * n - 1;
-    if (coord_bound) *coord_bound = (float)((scale + margin) * (1.0 + 1e-6));
+    out->d_nodes = d_nodes;
+    out->n_nodes = 2 * n - 1;
+    out->coord_bound = (float)((scale + margin) * (1.0 + 1e-6));
+    out->d_wide = d_wide;
+    out->n_wide = n_wide;
+    out->wide_depth = wide_depth;
     d_nodes = nullptr;
+    d_wide = nullptr;
     rc = 0;
 done:
     for (void *p : {(void *)d_boxes, (void *)d_inner_box, (void *)d_prim, (void *)d_ids, (void *)d_ids2, (void *)d_left,
                     (void *)d_right, (void *)d_pin, (void *)d_pleaf, (void *)d_first, (void *)d_last, (void *)d_arrived,
-                    (void *)d_codes, (void *)d_codes2, (void *)d_order, d_tmp, (void *)d_nodes})
+                    (void *)d_codes, (void *)d_codes2, (void *)d_order, d_tmp, (void *)d_nodes, (void *)d_wide, (void *)d_depth,
+                    (void *)d_even, (void *)d_widx, (void *)d_maxdepth, d_scan_tmp})
         (void)hipFree(p);
     return rc;
 }

@@ -189,6 +189,8 @@ struct DevScene {
     const int32_t *class_ids;   // index within a group, and their scene indices
     int32_t class_end[6];       // where each group ends in class_geom
     float bvh_bound;            // no bound of any hierarchy node exceeds this in magnitude
+    const PtxWideNode *wide;    // the hierarchy four children to a node (scenes whose node arrays exceed the L2 caches), or nullptr
+    int32_t n_wide, wide_stack_bound;  // wide_stack_bound: no walk of `wide` ever holds more entries on its stack
 };
 
 struct DevRender {
@@ -232,6 +234,8 @@ enum { RI_ONE = -1, RI_ZERO = -2 };
 struct LaneStore {
     double *base;  // &lds_d[0][threadIdx.x]
     int *ibase;    // &lds_i[0][threadIdx.x]
+    int pend;      // first of the LS_PEND_N double slots of the pending light sample (hierarchy kernels; LS_PEND unless the
+                   // kernel parks no samples)
     __device__ __forceinline__ double get(int slot) const { return base[slot * PTX_BLOCK]; }
     __device__ __forceinline__ void put(int slot, double v) const { base[slot * PTX_BLOCK] = v; }
     __device__ __forceinline__ int geti(int slot) const { return ibase[slot * PTX_BLOCK]; }
@@ -240,7 +244,7 @@ struct LaneStore {
 #define PTX_LANE_STORE(ls)                                   \
     __shared__ double lds_d_[LS_DSLOTS][PTX_BLOCK];          \
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];             \
-    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]}
+    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x], LS_PEND}
 
 // ------------------------------------------------------- transforms
 template <typename MP>
@@ -1428,11 +1432,11 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
             pend.ed = dl * fast_rsqrt(d2);
-            ls.put(LS_PEND + 0, dot3(n, pend.ed));
-            ls.put(LS_PEND + 1, fast_rcp(d2));
-            ls.put(LS_PEND + 2, inv_keep);
-            ls.put(LS_PEND + 3, ps.col.x * R);
-            ls.put(LS_PEND + 4, ps.col.y * G);
+            ls.put(ls.pend + 0, dot3(n, pend.ed));
+            ls.put(ls.pend + 1, fast_rcp(d2));
+            ls.put(ls.pend + 2, inv_keep);
+            ls.put(ls.pend + 3, ps.col.x * R);
+            ls.put(ls.pend + 4, ps.col.y * G);
             pend.cb = ps.col.z * B;
             result = SH_SHADOW;
         }
@@ -1444,11 +1448,11 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
 }
 
 __device__ __forceinline__ void shadow_pending_load(const LaneStore &ls, ShadowPending &pend) {
-    pend.n_ed = ls.get(LS_PEND + 0);
-    pend.rcp_d2 = ls.get(LS_PEND + 1);
-    pend.inv_keep = ls.get(LS_PEND + 2);
-    pend.cr = ls.get(LS_PEND + 3);
-    pend.cg = ls.get(LS_PEND + 4);
+    pend.n_ed = ls.get(ls.pend + 0);
+    pend.rcp_d2 = ls.get(ls.pend + 1);
+    pend.inv_keep = ls.get(ls.pend + 2);
+    pend.cr = ls.get(ls.pend + 3);
+    pend.cg = ls.get(ls.pend + 4);
 }
 
 // sh: result of the shadow query from ps.p0 along pend.ed (os = ps.os).  Reference PathTracer.c:428-445.
@@ -1579,6 +1583,113 @@ __device__ __forceinline__ void query_leaf(const DevScene &sc, V3 p0, V3 d, Quer
         q.best = __double2float_ru(lam);
     }
     q.leaf = -1;
+}
+
+// ------------------------------------------------ the same query over the four-wide hierarchy (PtxWideNode)
+// For scenes whose node arrays are far larger than the L2 caches a step of the walk waits for device memory.  The wide
+// walk fetches one whole 128-byte line per step -- the boxes of four children -- and keeps the children it has yet to
+// visit on a stack of its own: the first WIDE_STACK_LDS entries in the lane's LDS slots, the rest (deep trees only) in a
+// region of device memory set aside per lane.  Query::node counts the entries on the stack; the query is over when the
+// stack is empty and no leaf waits.  Children are pushed in the order PtxWideNode::order gives for the ray's octant,
+// farthest first, so the nearest is popped first and its hits cull the others when their turn comes.  The box test is
+// query_step's (single precision with slack, never rejecting a box the double-precision test enters); which bound of
+// an axis a ray reaches first is picked by the sign of its direction, since one array serves all directions.  The
+// ray's own surface (os) is dropped when its leaf comes off the stack.
+// The closest hit, ties included, does not depend on the order of the visits, so the result has closest_hit_all's bits.
+#define WIDE_STACK_LDS 20
+#define PTX_WIDE_SPILL 44  // entries of device memory per lane behind the LDS part
+// (the LDS part through a pointer that says so: a pointer that may be either LDS or device memory makes every access a
+// flat one)
+typedef __attribute__((address_space(3))) int *LdsIntPtr;
+struct WideStack {
+    LdsIntPtr lds;  // &stack[0][lane] of the wave's LDS stack: entry e of this lane is lds[e * PTX_BLOCK]
+    int *spill;   // entry e >= lds_n of this lane is spill[(e - lds_n) * spill_stride]
+    size_t spill_stride;
+    int lds_n;    // entries kept in LDS: WIDE_STACK_LDS (fewer only in tests of the spill path)
+    __device__ __forceinline__ void put(int e, int w) const {
+        if (e < lds_n) lds[e * PTX_BLOCK] = w;
+        else spill[(size_t)(e - lds_n) * spill_stride] = w;
+    }
+    __device__ __forceinline__ int get(int e) const {
+        return e < lds_n ? lds[e * PTX_BLOCK] : spill[(size_t)(e - lds_n) * spill_stride];
+    }
+};
+__device__ __forceinline__ void query_begin_wide(const DevScene &sc, V3 p0, V3 d, int os, Query &q, const WideStack &st) {
+    q.h.lambda = INFINITY;
+    q.h.obj = -1;
+    q.h.part = 0;
+    const double dd = dot3(d, d);
+    const double inv_dd = fast_rcp(dd);
+    list_hits_nb(sc, p0, d, os, dd, inv_dd, q.h);
+    q.best = __double2float_ru(q.h.lambda);
+    q.ix = rcp_for_slab32(d.x);
+    q.iy = rcp_for_slab32(d.y);
+    q.iz = rcp_for_slab32(d.z);
+    query_axis32(p0.x, q.ix, sc.bvh_bound, q.nx, q.fx);
+    query_axis32(p0.y, q.iy, sc.bvh_bound, q.ny, q.fy);
+    query_axis32(p0.z, q.iz, sc.bvh_bound, q.nz, q.fz);
+    q.base = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2;  // the ray's octant
+    st.lds[0] = ~0;  // the root
+    q.node = 1;
+    q.leaf = -1;
+}
+// One entry off the stack: a leaf is noted in Query::leaf (the lane then pauses, as in query_step; the ray's own
+// surface is dropped); a wide node is fetched, its four child boxes tested, and the children the ray enters pushed,
+// farthest first.
+// Which bound of an axis the ray reaches first is chosen by address: the lower and upper bounds of an axis are adjacent
+// 16-byte words of the node, and the octant's sign bit picks which of the two is loaded as "near" (a select per value
+// would cost 24 instructions a step).  While every lane of the wave has its whole stack in LDS -- always, but for trees
+// of unusual depth -- popping is one LDS read and pushing one LDS write per child without a branch (a child the ray
+// does not enter is written too and overwritten by the next push).
+__device__ __forceinline__ void query_step_wide(const DevScene &sc, int os, Query &q, const WideStack &st) {
+    const int top = --q.node;
+    int e;
+    if (__ballot(top >= st.lds_n) == 0ULL) e = st.lds[top * PTX_BLOCK];
+    else e = st.get(top);
+    if (e >= 0) {
+        q.leaf = (e & PTX_LEAF_INDEX) != os ? e : -1;
+        return;
+    }
+    const char *nodes = (const char *)sc.wide;
+    const uint32_t at = (uint32_t)~e << 7;  // byte offset of the node (arrays beyond 4 GB are not built)
+    const uint32_t sx = (q.base & 1) << 4, sy = (q.base & 2) << 3, sz = (q.base & 4) << 2;  // 16 where the ray travels downward
+    const float4 x0 = *(const float4 *)(nodes + (at | sx)), x1 = *(const float4 *)(nodes + (at | (sx ^ 16u)));
+    const float4 y0 = *(const float4 *)(nodes + (at | 32u | sy)), y1 = *(const float4 *)(nodes + (at | 32u | (sy ^ 16u)));
+    const float4 z0 = *(const float4 *)(nodes + (at | 64u | sz)), z1 = *(const float4 *)(nodes + (at | 64u | (sz ^ 16u)));
+    const int4 ch = *(const int4 *)(nodes + (at | 96u));
+    const uint2 ord = *(const uint2 *)(nodes + (at | 112u));
+    int hits = 0;
+#define PTX_WIDE_CHILD(c, bit)                                                                                              \
+    {                                                                                                                       \
+        const float lmin = fmaxf(fmaxf(fmaf(x0.c, q.ix, -q.nx), fmaf(y0.c, q.iy, -q.ny)), fmaf(z0.c, q.iz, -q.nz));         \
+        const float lmax = fminf(fminf(fmaf(x1.c, q.ix, -q.fx), fmaf(y1.c, q.iy, -q.fy)), fmaf(z1.c, q.iz, -q.fz));         \
+        hits |= (!(lmin > lmax) && !(lmax < 0) && !(lmin > q.best)) ? (1 << bit) : 0;                                       \
+    }
+    PTX_WIDE_CHILD(x, 0)
+    PTX_WIDE_CHILD(y, 1)
+    PTX_WIDE_CHILD(z, 2)
+    PTX_WIDE_CHILD(w, 3)
+#undef PTX_WIDE_CHILD
+    const unsigned order = ((q.base & 4 ? ord.y : ord.x) >> (8 * (q.base & 3))) & 255u;
+    if (__ballot(q.node + 4 > st.lds_n) == 0ULL) {
+#pragma unroll
+        for (int t = 3; t >= 0; t--) {
+            const int s = (order >> (2 * t)) & 3;
+            const int w = s & 2 ? (s & 1 ? ch.w : ch.z) : (s & 1 ? ch.y : ch.x);
+            st.lds[q.node * PTX_BLOCK] = w;
+            q.node += (hits >> s) & 1;
+        }
+    } else {
+#pragma unroll
+        for (int t = 3; t >= 0; t--) {
+            const int s = (order >> (2 * t)) & 3;
+            if ((hits >> s) & 1) {
+                const int w = s & 2 ? (s & 1 ? ch.w : ch.z) : (s & 1 ? ch.y : ch.x);
+                st.put(q.node, w);
+                q.node++;
+            }
+        }
+    }
 }
 
 // The glossy perturbation d += refl_sig * (N1, N2, N3) (reference PathTracer.c:460-464) for every lane of the

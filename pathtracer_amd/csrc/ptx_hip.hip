@@ -20,6 +20,7 @@
 #include "ptx_device.h"
 #include "ptx_hip.h"
 #include "ptx_internal.h"
+#include "ptx_trace_bvh.h"
 
 // ------------------------------------------------------------------ kernels
 // Rendering is two kernels.  The reference folds each finished path into its pixel's accumulator with a
@@ -86,9 +87,6 @@ struct TraceShape {
     static constexpr int waves_per_simd = (USE_BVH || !PINHOLE) ? 3 : 4;
 };
 
-#ifndef PTX_BVH_WAVES
-#define PTX_BVH_WAVES 3
-#endif
 // One lane per pixel of the tile; a lane starts its pixel's next sample as soon as its path ends (path
 // regeneration), so the wave stays full until its slowest pixel is done with the range.
 // PINHOLE: the aperture is zero, so every sample of a pixel starts along the same direction.
@@ -100,7 +98,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
                     double *__restrict__ samples, unsigned long long *__restrict__ stats) {
     __shared__ double lds_d_[LS_PARKED + 9][PTX_BLOCK];
     __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
-    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
+    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x], LS_PEND};
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x % n_tiles, sub = blockIdx.x / n_tiles;
     const int tiles_x = (rp.sx + 7) >> 3;
@@ -219,315 +217,6 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
     // (as a loop: unrolled, these 48 lane permutes at the end change the register assignment of the loop above, which
     // then runs 0.9 % slower)
 #pragma nounroll
-    for (int off = 32; off > 0; off >>= 1) {
-        c0 += __shfl_down(c0, off);
-        c1 += __shfl_down(c1, off);
-        c2 += __shfl_down(c2, off);
-        c3 += __shfl_down(c3, off);
-    }
-    if (lane == 0) {
-        atomicAdd(&stats[0], c0);
-        atomicAdd(&stats[1], c1);
-        atomicAdd(&stats[2], c2);
-        if (c3) atomicAdd(&stats[3], c3);
-    }
-}
-
-// The tracing kernel for scenes with a hierarchy.  Same tiles, sample ranges and sample buffer as k_trace_samples,
-// but a lane does not run whole closest-hit queries: it carries one query (of a path segment or of a shadow ray)
-// at a time through the walk (query_begin / query_step / query_leaf), and the loop alternates between
-//   walking  -- every lane with an unfinished query visits hierarchy nodes, until at most exit_lanes lanes are
-//               still walking and there is something to shade; a ray that needs thirty steps no longer keeps
-//               sixty-three rays that needed five waiting, it simply goes on in the next walking phase;
-//   shading  -- the lanes whose query has finished take its result.  Resolving a shadow ray (apply_shadow) is
-//               cheap and done whenever one is ready; the surface interaction (shade_hit) is a few thousand
-//               instructions that the wave pays for whatever the number of lanes in it, so it waits until
-//               shade_min lanes have a closest hit to shade (or nothing else can make progress).  Most lanes thus
-//               still move in step -- query, shade, shadow query, resolve -- and only the stragglers drift.
-// Leaves are not tested where they are met: a lane pauses at a leaf whose box it enters, and the wave tests the
-// leaves of leaf_batch lanes together (or of those there are, when no lane can step).
-// Work is handed out while the kernel runs.  A work tile is what a wave of k_trace_samples traces, sub_len samples
-// of the 64 pixels of a tile; here the waves are persistent (the grid is what the GPU holds at once), a wave takes
-// the next work tile from a counter in device memory (*work_counter, zero at launch) whenever its lanes have used
-// up the pixels of the last one, and a lane that has finished its pixel's samples takes any pixel of the wave's
-// current work tile that has not been handed out.  Paths differ much in length (a pixel's 25 samples take between
-// half and twice the average number of queries), and with fixed pixels a wave ends up waiting for its slowest
-// pixel with most lanes idle; this way every lane has work until the image runs out.
-// Every path performs the operations of bounce() in the same order, so the image has the same bits.
-template <int FLAGS, bool PINHOLE>
-__global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
-    k_trace_samples_bvh(DevScene sc, DevRender rp, int k0, int k1, int sub_len, int n_tiles, int n_work, size_t stride,
-                        double *__restrict__ samples, unsigned long long *__restrict__ stats, unsigned int *__restrict__ work_counter,
-                        int exit_lanes, int leaf_batch, int shade_min, int burst, int small_run, int lds_nodes) {
-    __shared__ double lds_d_[LS_PEND + LS_PEND_N][PTX_BLOCK];
-    __shared__ int lds_i_[LS_ISLOTS][PTX_BLOCK];
-    const LaneStore ls{&lds_d_[0][threadIdx.x], &lds_i_[0][threadIdx.x]};
-    const int lane = threadIdx.x & 63;
-    const int tiles_x = (rp.sx + 7) >> 3;
-    const int n_nodes = sc.n_bvh_nodes;
-#ifdef PTX_LDS_TOP
-    // Experiment (PTX_WALK_LDS_NODES=n, n <= 12, in a build with -DPTX_LDS_TOP): the first n entries of every octant's node
-    // array in LDS, a copy per wave.  The arrays are in depth-first order, so these are the root and the chain of nearer
-    // children below it: the first steps of every walk.
-    __shared__ float4 lds_top_[8 * PTX_LDS_TOP_MAX * 2];
-    if (lds_nodes > n_nodes) lds_nodes = n_nodes;
-    for (int t = lane; t < 8 * lds_nodes * 2; t += 64) {
-        const int oct = t / (2 * lds_nodes), rest = t - oct * 2 * lds_nodes;
-        const int src_oct = sc.bvh_per_octant ? oct : 0;
-        lds_top_[2 * oct * PTX_LDS_TOP_MAX + rest] = ((const float4 *)(sc.bvh + (size_t)src_oct * n_nodes))[rest];
-    }
-    __syncthreads();
-    const float4 *top = lds_top_;
-#else
-    const float4 *top = nullptr;
-    lds_nodes = 0;
-#endif
-    // the lane's pixel and sample range (none yet: k == ke)
-    int i = 0, j = 0, ks = 0, ke = 0, k = 0;
-    size_t pix = 0;
-    // the wave's current work tile and which of its pixels have not been handed out; both the same in every lane
-    int cur_tile = 0, cur_sub = 0;
-    unsigned long long cur_free = 0ULL;
-    bool exhausted = false;  // the counter has run past the last work tile
-
-    enum { M_NONE = 0, M_CLOSEST = 1, M_SHADOW = 2 };
-    Counters cnt = {0, 0, 0};
-    uint32_t paths = 0;
-    Path ps;
-    V3 shadow_d = mk(0, 0, 0);  // direction of the lane's shadow query
-    double shadow_cb = 0;       // the one field of its ShadowPending besides the direction that stays in registers
-    Query q;
-#ifdef PTX_PHASE_TIMERS
-    // per wave: cycles spent in each part of the loop, how often it ran and with how many lanes
-    enum { D_TOTAL, D_SHADE, D_SHADOW, D_SETUP, D_STEPS, D_LEAF, D_REGEN, D_N_ITER, D_N_SHADE, D_L_SHADE, D_N_SHADOW, D_L_SHADOW,
-           D_N_SETUP, D_L_SETUP, D_N_BURST, D_L_BURST, D_N_LEAF, D_L_LEAF, D_N_REGEN, D_L_REGEN, D_L_STEPS, D_L_ACTIVE };
-    unsigned long long dbg[PTX_N_DBG] = {};
-    const long long dbg_t0 = clock64();
-    long long dbg_t;
-#define DBG_BEGIN() (dbg_t = clock64())
-#define DBG_END(slot_cyc, slot_n, slot_l, pred)                 \
-    do {                                                        \
-        const int lanes_ = __popcll(__ballot(pred));            \
-        dbg[slot_cyc] += (unsigned long long)(clock64() - dbg_t); \
-        dbg[slot_n] += lanes_ > 0;                              \
-        dbg[slot_l] += lanes_;                                  \
-    } while (0)
-#else
-#define DBG_BEGIN() ((void)0)
-#define DBG_END(a, b, c, d) ((void)0)
-#endif
-    q.node = n_nodes;
-    q.leaf = -1;
-    int mode = M_NONE;   // what the lane's query is for
-    bool fresh = false;  // the query has yet to be set up
-    bool over = false;   // M_SHADOW: the path ends when the shadow ray is resolved
-    for (;;) {
-        // ---- shading: lanes whose query is over
-        bool ended = false;
-        bool shaded = false;  // shade_hit ran in this iteration
-        {
-            const bool ready = mode != M_NONE && !fresh && q.node >= n_nodes && q.leaf < 0;
-            const bool ready_closest = ready && mode == M_CLOSEST;
-            const int n_closest = __popcll(__ballot(ready_closest));
-            const int n_busy = __popcll(__ballot(mode != M_NONE && !ready));
-            const int n_active = __popcll(__ballot(mode != M_NONE));
-            const bool ready_shadow = ready && mode == M_SHADOW;
-            const bool shade_now = n_closest > 0 && (64 * n_closest >= shade_min * n_active || n_busy == 0);
-            const int n_shadow = __popcll(__ballot(ready_shadow));
-            if (n_shadow > 0 && (n_shadow >= small_run || shade_now || n_busy == 0)) {
-                DBG_BEGIN();
-                if (ready_shadow) {
-                    ShadowPending pend;
-                    pend.ed = shadow_d;
-                    pend.cb = shadow_cb;
-                    shadow_pending_load(ls, pend);
-                    apply_shadow(sc, rp, ps, q.h, pend);
-                    ended = over;
-                    mode = M_CLOSEST;
-                    fresh = true;
-                }
-                DBG_END(D_SHADOW, D_N_SHADOW, D_L_SHADOW, ready_shadow);
-            }
-            shaded = shade_now;
-            if (shade_now) {
-                DBG_BEGIN();
-                double glossy = 0;
-                if (ready_closest) {
-                    ShadowPending pend;
-                    pend.ed = mk(0, 0, 0);
-                    pend.cb = 0;
-                    const int r = shade_hit<FLAGS>(sc, rp, ls, ps, cnt, q.h, glossy, pend, over);
-                    ended = r == SH_END;
-                    mode = r == SH_SHADOW ? M_SHADOW : M_CLOSEST;
-                    fresh = true;
-                    // (unconditional: a lane without a shadow query does not read them, and the old values do not
-                    // have to be kept through shade_hit)
-                    shadow_d = pend.ed;
-                    shadow_cb = pend.cb;
-                }
-                glossy_service(ps, glossy, lane);
-                DBG_END(D_SHADE, D_N_SHADE, D_L_SHADE, ready_closest);
-            }
-        }
-#ifdef PTX_PHASE_TIMERS
-        dbg[D_N_ITER]++;
-        dbg[D_L_ACTIVE] += __popcll(__ballot(mode != M_NONE || k < ke || !exhausted));
-        const bool dbg_regen = ended || (mode == M_NONE && k < ke);
-#endif
-        DBG_BEGIN();
-        if (ended) {
-            // four samples make a 128-byte line of the lane's stream, written once and whole (see k_trace_samples)
-            const int slot = (k - ks) & 3;
-            double4 *out = (double4 *)(samples + (pix * stride + (size_t)(k - k0)) * PTX_SAMPLE_DOUBLES);
-            if (slot == 3) {
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    out[c - 3] = make_double4(ls.get(LS_PARKED + 3 * c), ls.get(LS_PARKED + 3 * c + 1), ls.get(LS_PARKED + 3 * c + 2), 0.0);
-                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
-            } else if (k + (3 - slot) >= ke) {
-                out[0] = make_double4(ps.I.x, ps.I.y, ps.I.z, 0.0);
-            } else {
-                ls.put(LS_PARKED + 3 * slot, ps.I.x);
-                ls.put(LS_PARKED + 3 * slot + 1, ps.I.y);
-                ls.put(LS_PARKED + 3 * slot + 2, ps.I.z);
-            }
-            mode = M_NONE;
-            fresh = false;
-            k++;
-            paths++;
-        }
-        // ---- a new pixel for the lanes that have done theirs
-        for (;;) {
-            const bool need = mode == M_NONE && k >= ke;
-            const unsigned long long m_need = __ballot(need);
-            if (m_need == 0ULL) break;
-            if (cur_free == 0ULL) {
-                if (exhausted) break;
-                unsigned int wt = 0;
-                if (lane == 0) wt = atomicAdd(work_counter, 1u);
-                wt = __shfl(wt, 0);
-                if (wt >= (unsigned int)n_work) {
-                    exhausted = true;
-                    break;
-                }
-                cur_tile = (int)(wt % (unsigned int)n_tiles);
-                cur_sub = (int)(wt / (unsigned int)n_tiles);
-                const int tx = cur_tile % tiles_x, ty = cur_tile / tiles_x;
-                cur_free = __ballot(tx * 8 + (lane & 7) < rp.sx && ty * 8 + (lane >> 3) < rp.rows_owned);
-                continue;
-            }
-            // the r-th lane in need takes the r-th free pixel
-            const int r = __popcll(m_need & ((1ULL << lane) - 1ULL));
-            const int n_free = __popcll(cur_free), n_need = __popcll(m_need);
-            if (need && r < n_free) {
-                int pos = 0, left = r;  // position of the r-th set bit of cur_free
-#pragma unroll
-                for (int w = 32; w >= 1; w >>= 1) {
-                    const int c = __popcll((cur_free >> pos) & ((1ULL << w) - 1ULL));
-                    if (left >= c) {
-                        left -= c;
-                        pos += w;
-                    }
-                }
-                const int tx = cur_tile % tiles_x, ty = cur_tile / tiles_x;
-                i = tx * 8 + (pos & 7);
-                const int jl = ty * 8 + (pos >> 3);
-                j = ptx_global_row(jl, rp.rank, rp.n_ranks, rp.band_rows);
-                pix = (size_t)jl * rp.sx + i;
-                ks = k0 + cur_sub * sub_len;
-                ke = ks + sub_len < k1 ? ks + sub_len : k1;
-                k = ks;
-                if (PINHOLE) {
-                    primary_ray(sc, rp, ls, i, j, ks, ps);
-                    ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
-                }
-            }
-            // drop the pixels just handed out: the lowest min(n_need, n_free) set bits
-            const int taken = n_need < n_free ? n_need : n_free;
-            unsigned long long rest = cur_free;
-            for (int t = 0; t < taken; t++) rest &= rest - 1ULL;
-            cur_free = rest;
-        }
-        // ---- a pixel's next sample (not for a few lanes at a time: they wait for the iteration in which the others
-        // have been shaded, unless the wave has nothing else to do)
-        const int n_start = __popcll(__ballot(mode == M_NONE && k < ke));
-        const bool start_now = n_start >= small_run || shaded || __ballot(mode != M_NONE && (fresh || q.node < n_nodes || q.leaf >= 0)) == 0ULL;
-        if (start_now && mode == M_NONE && k < ke) {
-            if (PINHOLE) primary_ray_cached(sc, rp, ls, i, j, k, ps);
-            else primary_ray(sc, rp, ls, i, j, k, ps);
-            if (rp.max_depth < 1) {  // reference PathTracer.c:273 with depth = 1: the path is over before its first query
-                mode = M_SHADOW;
-                over = true;
-                q.h.obj = -1;
-            } else {
-                mode = M_CLOSEST;
-                fresh = true;
-            }
-        }
-        DBG_END(D_REGEN, D_N_REGEN, D_L_REGEN, dbg_regen);
-        if (__ballot(mode != M_NONE || k < ke) == 0ULL) break;
-        // ---- the next query of the lanes that have one: the primitives every ray tests
-        DBG_BEGIN();
-#ifdef PTX_PHASE_TIMERS
-        const bool dbg_fresh = fresh;
-#endif
-        if (fresh) {
-            V3 qd;
-            if (mode == M_CLOSEST) {
-                ps.d = norm3(ps.d);
-                cnt.closest++;
-                qd = ps.d;
-            } else {
-                cnt.shadow++;
-                qd = shadow_d;
-            }
-            query_begin(sc, ps.p0, qd, ps.os, q);
-            fresh = false;
-        }
-        DBG_END(D_SETUP, D_N_SETUP, D_L_SETUP, dbg_fresh);
-        // ---- walking: bursts of up to `burst` steps per lane, with the wave-level decisions in between
-        const int n_active = __popcll(__ballot(mode != M_NONE));
-        for (;;) {
-            DBG_BEGIN();
-#ifdef PTX_PHASE_TIMERS
-            const bool dbg_walking = q.leaf < 0 && q.node < n_nodes;
-            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) {
-                query_step(sc, ps.os, q, top, lds_nodes);
-                dbg[D_L_STEPS]++;
-            }
-#else
-            for (int st = 0; st < burst && q.leaf < 0 && q.node < n_nodes; st++) query_step(sc, ps.os, q, top, lds_nodes);
-#endif
-            DBG_END(D_STEPS, D_N_BURST, D_L_BURST, dbg_walking);
-            const bool paused = q.leaf >= 0;
-            const bool stepping = !paused && q.node < n_nodes;
-            const int n_step = __popcll(__ballot(stepping)), n_paused = __popcll(__ballot(paused));
-            if (n_paused > 0 && (n_paused >= leaf_batch || n_step == 0)) {
-                DBG_BEGIN();
-                if (paused) query_leaf(sc, ps.p0, mode == M_SHADOW ? shadow_d : ps.d, q);
-                DBG_END(D_LEAF, D_N_LEAF, D_L_LEAF, paused);
-                continue;
-            }
-            if (n_step == 0) break;
-            if (n_step + n_paused <= exit_lanes) {
-                const bool done = mode != M_NONE && !stepping && !paused;
-                const int n_closest = __popcll(__ballot(done && mode == M_CLOSEST));
-                if (64 * n_closest >= shade_min * n_active || __popcll(__ballot(done && mode == M_SHADOW)) >= small_run) break;
-            }
-        }
-    }
-    #ifdef PTX_PHASE_TIMERS
-    dbg[D_TOTAL] = (unsigned long long)(clock64() - dbg_t0);
-    for (int c = 0; c < PTX_N_DBG; c++) {
-        // cycle counts and invocation counts are the same in every lane; D_L_STEPS is per lane
-        unsigned long long v = dbg[c];
-        if (c == D_L_STEPS)
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0 && v) atomicAdd(&stats[PTX_STATS_DBG + c], v);
-    }
-#endif
-    // one set of atomics per wave
-    unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_down(c0, off);
         c1 += __shfl_down(c1, off);
@@ -689,6 +378,8 @@ struct ptx_context {
     DevScene sc{};
     void *d_geom = nullptr, *d_mat = nullptr, *d_lights = nullptr, *d_images = nullptr, *d_texels = nullptr;
     void *d_list_geom = nullptr, *d_list_ids = nullptr, *d_bvh = nullptr, *d_class_geom = nullptr, *d_class_ids = nullptr;
+    void *d_wide = nullptr;   // the hierarchy four children to a node (large scenes), or null
+    int *d_spill = nullptr;   // stack entries beyond the LDS part of the wide walk's stack, per lane of the largest grid
     bool use_bvh = false;
     int n_objects = 0;
     // render
@@ -706,10 +397,11 @@ struct ptx_context {
 
 static void free_scene(ptx_context *c) {
     for (void *q : {c->d_geom, c->d_mat, c->d_lights, c->d_images, c->d_texels, c->d_list_geom, c->d_list_ids, c->d_bvh, c->d_class_geom,
-                    c->d_class_ids})
+                    c->d_class_ids, c->d_wide, (void *)c->d_spill})
         (void)hipFree(q);
     c->d_geom = c->d_mat = c->d_lights = c->d_images = c->d_texels = nullptr;
-    c->d_list_geom = c->d_list_ids = c->d_bvh = c->d_class_geom = c->d_class_ids = nullptr;
+    c->d_list_geom = c->d_list_ids = c->d_bvh = c->d_class_geom = c->d_class_ids = c->d_wide = nullptr;
+    c->d_spill = nullptr;
     c->have_scene = false;
 }
 static void free_render(ptx_context *c) {
@@ -983,7 +675,7 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
             class_end[cls] = (int32_t)w;
         }
     }
-    PtxBvhNode *d_bvh = nullptr;
+    PtxBvhBuilt built;
     int n_bvh_nodes = 0;
     float bvh_bound = 0;
     // One node array per octant of ray directions (512 bytes per primitive in all; +56 % on the 8000-cube sponge and
@@ -1004,11 +696,34 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
         // Topology: surface-area heuristic on the host up to 4 M primitives (PTX_BVH_BUILD=lbvh or sah overrides)
         bool use_sah = leaves.size() <= (4u << 20);
         if (const char *e = getenv("PTX_BVH_BUILD")) use_sah = strcmp(e, "lbvh") != 0;
-        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, use_sah, c->stream, &d_bvh, &n_bvh_nodes, &bvh_bound, err) != 0)
+        // Node arrays far larger than the L2 caches (eight of 4 MB): the four-wide form of the tree as well, which the
+        // render kernel then walks (PTX_BVH_WALK=wide or binary overrides the choice; the images are the same).
+        const size_t node_bytes = (size_t)(2 * leaves.size() - 1) * sizeof(PtxBvhNode) * bvh_orders;
+        bool want_wide = node_bytes > ((size_t)32 << 20);
+        if (const char *e = getenv("PTX_BVH_WALK")) want_wide = strcmp(e, "wide") == 0;
+        if (ptx_bvh_build(boxes.data(), leaves.data(), (int)leaves.size(), bvh_orders, use_sah, want_wide, c->stream, &built, err) != 0)
             return fail(PTX_EDEVICE, "ptx_scene_upload: hierarchy build failed: " + err);
+        n_bvh_nodes = built.n_nodes;
+        bvh_bound = built.coord_bound;
     }
-    c->d_bvh = d_bvh;
+    c->d_bvh = built.d_nodes;
+    c->d_wide = built.d_wide;
     c->use_bvh = n_bvh_nodes > 0;
+    // The wide walk's stack never holds more than three pending children per wide node on the way down plus the four
+    // of the last: a tree too deep for the stack (LDS part plus PTX_WIDE_SPILL entries of device memory per lane) is
+    // walked in its binary form instead.
+    int wide_stack_bound = 0;
+    if (built.d_wide) {
+        wide_stack_bound = 3 * built.wide_depth + 1;
+        if (wide_stack_bound > WIDE_STACK_LDS + PTX_WIDE_SPILL) {
+            (void)hipFree(c->d_wide);
+            c->d_wide = nullptr;
+        } else {
+            // one region per lane of the largest grid the render kernel is launched with (persistent waves: what the GPU holds)
+            const size_t lanes = (size_t)c->n_cus * 4 * PTX_BVH_WAVES * PTX_BLOCK;
+            HIPCHK(hipMalloc((void **)&c->d_spill, lanes * PTX_WIDE_SPILL * sizeof(int)));
+        }
+    }
     HIPCHK(hipMalloc(&c->d_list_geom, list_geom.size() * sizeof(DevGeom)));
     HIPCHK(hipMalloc(&c->d_list_ids, (list_ids.size() ? list_ids.size() : 1) * sizeof(int32_t)));
     HIPCHK(hipMemcpy(c->d_list_geom, list_geom.data(), list_geom.size() * sizeof(DevGeom), hipMemcpyHostToDevice));
@@ -1045,6 +760,9 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
     d.n_bvh_nodes = n_bvh_nodes;
     d.bvh_per_octant = bvh_orders == 8;
     d.bvh_bound = bvh_bound;
+    d.wide = (const PtxWideNode *)c->d_wide;
+    d.n_wide = c->d_wide ? built.n_wide : 0;
+    d.wide_stack_bound = c->d_wide ? wide_stack_bound : 0;
     d.n_objects = n; d.n_lights = s->n_lights; d.n_images = s->n_images; d.has_refraction = has_refr;
     const ptx_camera &cam = s->cam;
     for (int q = 0; q < 3; q++) { d.cam.e[q] = cam.e[q]; d.cam.w[q] = cam.w[q]; }
@@ -1122,6 +840,7 @@ extern "C" int ptx_render_begin_external(ptx_context *c, const ptx_render_params
 template <typename F>
 static void dispatch_flags_1(int flags, F &&f) {
     switch (flags & 7) {
+#ifndef PTX_ONLY_FLAGS7  // (experimental builds, tools/build_variants.sh: only the IS+ES+RR kernels, a quarter of the compile time)
     case 0: f(std::integral_constant<int, 0>()); break;
     case 1: f(std::integral_constant<int, 1>()); break;
     case 2: f(std::integral_constant<int, 2>()); break;
@@ -1129,6 +848,7 @@ static void dispatch_flags_1(int flags, F &&f) {
     case 4: f(std::integral_constant<int, 4>()); break;
     case 5: f(std::integral_constant<int, 5>()); break;
     case 6: f(std::integral_constant<int, 6>()); break;
+#endif
     default: f(std::integral_constant<int, 7>()); break;
     }
 }
@@ -1188,8 +908,22 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     if (const char *e = getenv("PTX_WAVES_PER_SLOT")) fill = std::max(1L, atol(e));
     const size_t node_bytes = (size_t)c->sc.n_bvh_nodes * sizeof(PtxBvhNode) * (c->sc.bvh_per_octant ? 8 : 1);
     const bool nodes_in_l2 = node_bytes <= ((size_t)32 << 20);  // eight L2 caches of 4 MB
+    bool wide = c->sc.wide != nullptr && sliced;                 // the four-wide walk (built for large node arrays only)
+    // entries of its stack kept in LDS (PTX_WIDE_LDS_ENTRIES lowers it, for tests of the part in device memory)
+    int stack_lds = WIDE_STACK_LDS;
+    if (const char *e = getenv("PTX_WIDE_LDS_ENTRIES")) stack_lds = std::max(4, std::min(WIDE_STACK_LDS, atoi(e)));
+    if (wide && c->sc.wide_stack_bound > stack_lds + PTX_WIDE_SPILL) wide = false;
     int exit_lanes = nodes_in_l2 ? 12 : 24, leaf_batch = nodes_in_l2 ? 4 : 8, shade_min = nodes_in_l2 ? 40 : 24,
         burst = nodes_in_l2 ? 6 : 4, small_run = 8;
+    // the four-wide walk: a step is four box tests and a stack operation, worth two or three steps of the binary walk, and a
+    // lane needs four or five of them for a query; short bursts, and the walk is left early (swept on the mesh of a
+    // million triangles, tools/sweep_walk.py: bursts of 2, 32 lanes, leaves tested sixteen at a time)
+    if (c->sc.wide != nullptr) {
+        exit_lanes = 32;
+        leaf_batch = 16;
+        shade_min = 24;
+        burst = 2;
+    }
     if (const char *e = getenv("PTX_WALK_EXIT_LANES")) exit_lanes = std::max(0, std::min(63, atoi(e)));
     if (const char *e = getenv("PTX_WALK_LEAF_BATCH")) leaf_batch = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("PTX_WALK_SHADE_MIN")) shade_min = std::max(1, std::min(64, atoi(e)));
@@ -1263,14 +997,11 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
             // persistent waves: as many as the GPU holds at once, or as there are work tiles
             const dim3 pgrid((unsigned)std::min<long>(n_tiles * n_sub, slots));
             if (B && sliced) {
-                if (pinhole)
-                    hipLaunchKernelGGL((k_trace_samples_bvh<F, true>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                       sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
-                else
-                    hipLaunchKernelGGL((k_trace_samples_bvh<F, false>), pgrid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
-                                       sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats, work_counter,
-                                       exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes);
+                const TraceBvhArgs a{c->sc, c->rp, ka, ka + nka, sub_len, (int)n_tiles, (int)(n_tiles * n_sub), (size_t)round_max, buf, c->d_stats,
+                                     work_counter, exit_lanes, leaf_batch, shade_min, burst, small_run, lds_nodes, c->d_spill, stack_lds};
+                if (wide) ptx_launch_trace_bvh_wide(F, pinhole, pgrid, c->stream, a);
+                else if (pinhole) launch_trace_bvh<F, true, false>(pgrid, c->stream, a);
+                else launch_trace_bvh<F, false, false>(pgrid, c->stream, a);
             } else if (pinhole)
                 hipLaunchKernelGGL((k_trace_samples<F, B, true>), grid, dim3(PTX_BLOCK), 0, c->stream, c->sc, c->rp, ka, ka + nka,
                                    sub_len_k, n_full, tail_len, (int)n_tiles, (size_t)round_max, buf, c->d_stats);

@@ -546,21 +546,35 @@ def test_hierarchy_order_does_not_change_results(name, scenes, monkeypatch):
     codes (built on the GPU) or from the surface-area heuristic (built on the host): the closest hit is the same
     primitive at the same distance, so first hits and rendered images are equal bit for bit."""
     got = {}
-    for orders, build in (("1", "lbvh"), ("8", "lbvh"), ("8", "sah"), ("1", "sah")):
+    # (the last three: the four-wide form of either tree, walked with a stack per lane, which scenes of this size do
+    # not get by themselves; the very last with all but four entries of that stack in device memory instead of LDS)
+    for orders, build, walk, lds in (("1", "lbvh", "binary", None), ("8", "lbvh", "binary", None), ("8", "sah", "binary", None),
+                                     ("1", "sah", "binary", None), ("8", "sah", "wide", None), ("1", "lbvh", "wide", None),
+                                     ("8", "sah", "wide", "4")):
         monkeypatch.setenv("PTX_BVH_ORDERS", orders)
         monkeypatch.setenv("PTX_BVH_BUILD", build)
+        monkeypatch.setenv("PTX_BVH_WALK", walk)
+        if lds is None:
+            monkeypatch.delenv("PTX_WIDE_LDS_ENTRIES", raising=False)
+        else:
+            monkeypatch.setenv("PTX_WIDE_LDS_ENTRIES", lds)
         dev = pt.Device(0)
         dev.scene_upload(scenes[name])
         hits = dev.first_hit(random_rays(scenes[name], 20000, 77))
         dev.render_begin(pt.make_params(48, 8, ALL, 0.05, seed=3))
         dev.render_passes(0, 4)
         rgb, wt = dev.download()
-        got[orders, build] = (hits, rgb, wt, dev.stats())
+        # the render kernels: with a lens and without (two variants each of the binary and the wide walk)
+        dev.render_begin(pt.make_params(40, 8, ALL, 0.0, seed=3))
+        dev.render_passes(0, 5)
+        rgb0, wt0 = dev.download()
+        got[orders, build, walk, lds] = (hits, rgb, wt, dev.stats(), rgb0, wt0)
         dev.close()
-    a = got["1", "lbvh"]
+    a = got["1", "lbvh", "binary", None]
     for b in got.values():
         assert np.array_equal(a[0]["obj"], b[0]["obj"]) and np.array_equal(a[0]["lambda"], b[0]["lambda"])
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
+        assert np.array_equal(a[4], b[4], equal_nan=True) and np.array_equal(a[5], b[5], equal_nan=True)
         assert a[3]["paths"] == b[3]["paths"] and a[3]["closest_hits"] == b[3]["closest_hits"]
 
 

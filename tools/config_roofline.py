@@ -53,6 +53,14 @@ def main():
     assert sum(list_by_type) == n_list, (list_by_type, n_list)
     flop = 24 * nodes + sum(c * (a + b) for c, a, b in zip(PRIM_FLOP, leaf, list_by_type)) + 40 * hits
     byts = 32 * nodes + 160 * sum(leaf) + 48 * texels
+    # The render kernel walks the four-wide form of the tree where the node arrays are far larger than the L2 caches: a
+    # visit there is one 128-byte node and four box tests.  The path kernel that counts visits walks the binary form, so
+    # the wide visits per ray come from the instrumented render kernel (tools/phase_timers.py: "node visits per query"),
+    # given as PTX_WIDE_VISITS_PER_RAY.
+    wide_visits = float(os.environ["PTX_WIDE_VISITS_PER_RAY"]) if "PTX_WIDE_VISITS_PER_RAY" in os.environ else None
+    if wide_visits is not None:
+        flop = 4 * 24 * wide_visits + sum(c * (a + b) for c, a, b in zip(PRIM_FLOP, leaf, list_by_type)) + 40 * hits
+        byts = 128 * wide_visits + 160 * sum(leaf) + 48 * texels
     # 2. rays per second at full size
     prm = pt.make_params(sx, depth, 7, ap, seed=1)
     dev.render_begin(prm)
@@ -72,7 +80,8 @@ def main():
     out = {
         "config": name, "size": sx, "depth": depth, "aperture": ap, "spp_timed": spp, "objects": int(len(o)),
         "kernel": os.environ.get("PTX_BVH_KERNEL", "sliced"),
-        "per_ray": {"node_visits": nodes, "leaf_tests_by_type": dict(zip(TYPE_NAMES, leaf)), "list_tests_by_type": dict(zip(TYPE_NAMES, list_by_type)),
+        "walk": "binary" if wide_visits is None else "four-wide (visits per ray from tools/phase_timers.py)",
+        "per_ray": {"node_visits": nodes, "wide_node_visits": wide_visits, "leaf_tests_by_type": dict(zip(TYPE_NAMES, leaf)), "list_tests_by_type": dict(zip(TYPE_NAMES, list_by_type)),
                     "hit_share": hits, "texel_lookups": texels},
         "flop_per_ray": flop, "bytes_per_ray": byts,
         "seconds": dt, "paths_per_s": sx * sx * spp / dt, "rays_per_s": rays / dt, "rays_per_path": rays / st["paths"],
