@@ -549,6 +549,39 @@ __device__ __forceinline__ void list_hits_nb(const DevScene &sc, V3 p0, V3 d, in
         h.part = win ? part : h.part;
     };
     int k = 0;
+#ifdef PTX_CULL32_PROBE
+    // Measurement only (not exact: no error bounds, ties ignored): what a single-precision first pass over the uniformly
+    // scaled spheres could save at best.  The nearest sphere is picked in single precision (centre and squared radius as
+    // floats in the unused transform words of the record) and only that one is intersected in double precision, its
+    // record fetched per lane.  An exact version needs error bounds on top of this pass; this is its lower bound in time.
+    {
+        const float px = (float)p0.x, py = (float)p0.y, pz = (float)p0.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+        const float ddf = (float)dd, tol = 1e-9f * ddf;
+        float best = INFINITY;
+        int arg = -1;
+#pragma unroll PTX_LIST_UNROLL
+        for (; k < sc.class_end[LC_FAST_SPHERE]; k++) {
+            const PTX_CONSTANT_AS float *s = (const PTX_CONSTANT_AS float *)&cg[k].m[0];
+            const float ox = px - s[0], oy = py - s[1], oz = pz - s[2];
+            const float B = ox * dx + oy * dy + oz * dz, C = ox * ox + oy * oy + oz * oz - s[3];
+            const float disc = B * B - ddf * C;
+            const float sq = __builtin_amdgcn_sqrtf(fabsf(disc));
+            const float t2 = -B - sq;
+            const float t = t2 > tol ? t2 : sq - B;
+            const bool win = !(disc < 0) & (ids[k] != os) & (t > tol) & (t < best);
+            best = win ? t : best;
+            arg = win ? k : arg;
+        }
+        if (arg >= 0) {
+            bool missed;
+            const double lam = isect_sphere_uniform_nb(sc.class_geom + arg, p0, d, dd, inv_dd, missed);
+            const int id = sc.class_ids[arg];
+            const bool win = !missed & (lam > PT_TOL) & (lam < h.lambda);
+            h.lambda = win ? lam : h.lambda;
+            h.obj = win ? id : h.obj;
+        }
+    }
+#endif
     // The first group meets an empty h and its members come in ascending scene index, so a strictly smaller lambda is
     // the whole rule there: of two equal ones the first tested has the lower index.
 #pragma unroll PTX_LIST_UNROLL
@@ -617,17 +650,33 @@ struct WalkCount {
 enum { PH_QUERY = 0, PH_SURFACE, PH_DIFFUSE, PH_LIGHT, PH_SHADOW_QUERY, PH_SHADOW_APPLY, PH_MIRROR, PH_REFRACT, PH_NEW_PATH, PH_GLOSSY,
        PH_SAMPLE_END, PH_LOOP };
 #ifdef PTX_PHASE_TIMERS
-#define PH_T() (COUNT ? clock64() : 0LL)
+// A part's cycles are what the wave's clock has advanced since the last part ended, whichever lanes ran either: the
+// time of the last PH_ADD is kept per wave (ph[PH_LAST]) beside the counters, so every cycle of the loop is counted
+// once, under the part whose end comes next.  (The scheduling barriers keep the compiler's scheduler from moving
+// arithmetic across the clock reads; what earlier passes sink from one part of the source into a later one -- the new
+// direction of a diffuse bounce, which nothing needs before the shadow query is over -- is counted where it runs.)
+#define PH_LAST (3 * PTX_N_PHASES - 1)
+__device__ __forceinline__ long long ph_clock() {
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PH_T() 0LL
 #define PH_ADD(wc, i, t0)                                                                  \
     do {                                                                                   \
         if (COUNT && (wc)->ph) {                                                           \
-            const long long dt_ = clock64() - (t0);                                        \
+            const long long now_ = ph_clock();                                             \
             const unsigned long long m_ = __ballot(1);                                     \
             if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                   \
+                /* (a clock read the compiler has hoisted above an earlier part's end counts nothing) */ \
+                const long long last_ = (long long)atomicMax(&(wc)->ph[PH_LAST], (unsigned long long)now_); \
+                const long long dt_ = now_ > last_ ? now_ - last_ : 0;                     \
                 atomicAdd(&(wc)->ph[3 * (i)], (unsigned long long)dt_);                    \
                 atomicAdd(&(wc)->ph[3 * (i) + 1], 1ULL);                                   \
                 atomicAdd(&(wc)->ph[3 * (i) + 2], (unsigned long long)__popcll(m_));       \
             }                                                                              \
+            (void)(t0);                                                                    \
         }                                                                                  \
     } while (0)
 #else
@@ -1195,7 +1244,6 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     Hit h = closest_hit_all<USE_BVH, COUNT>(sc, ps.p0, ps.d, ps.os, wc);
     PH_ADD(wc, PH_QUERY, ph_t);
     if (h.obj < 0) return true;
-    ph_t = PH_T();
     const DevMat &mt = sc.mat[h.obj];
     const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
     V3 p, n;
@@ -1230,7 +1278,6 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     int next_os = h.obj;
     PH_ADD(wc, PH_SURFACE, ph_t);
     if (dice <= diffusivity) {
-        ph_t = PH_T();
         V3 dir;
         double scale;
         if (FLAGS & PTX_USE_IS) {
@@ -1245,8 +1292,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         ps.d = dir;
         PH_ADD(wc, PH_DIFFUSE, ph_t);
         if (FLAGS & PTX_USE_ES) {
-            ph_t = PH_T();
-            double u = ps.rng.next();
+                double u = ps.rng.next();
             int li = 0;
             double acc = sc.lights[0].weight;
             while (acc < u && li + 1 < sc.n_lights) {
@@ -1259,11 +1305,9 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             V3 ed = dl * fast_rsqrt(d2);
             cnt.shadow++;
             PH_ADD(wc, PH_LIGHT, ph_t);
-            ph_t = PH_T();
-            Hit sh = closest_hit_all<USE_BVH, COUNT>(sc, p, ed, h.obj, wc);
+                Hit sh = closest_hit_all<USE_BVH, COUNT>(sc, p, ed, h.obj, wc);
             PH_ADD(wc, PH_SHADOW_QUERY, ph_t);
-            ph_t = PH_T();
-            int lit = 0;
+                int lit = 0;
             if (sh.obj >= 0) {
                 const DevMat &lm = sc.mat[sh.obj];
                 if (lm.is_light) {
@@ -1284,7 +1328,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             PH_ADD(wc, PH_SHADOW_APPLY, ph_t);
         }
     } else if (dice <= diffusivity + reflectivity) {
-        ph_t = PH_T();
+        ph_t = PH_T();  // (a branch of its own: the lanes in it have waited for the diffuse branch)
         if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
         n = norm3(n);
@@ -1309,6 +1353,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         next_os = -1;
         PH_ADD(wc, PH_REFRACT, ph_t);
     }
+    ph_t = PH_T();  // (the lanes meet again here)
     if (sc.has_refraction) {
         ls.put(LS_SRCN + 0, n.x);
         ls.put(LS_SRCN + 1, n.y);
@@ -1316,6 +1361,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     }
     ps.os = next_os;
     ps.depth++;
+    PH_ADD(wc, PH_DIFFUSE, ph_t);  // (the end of the bounce: work the compiler moved behind the last query, the new direction mostly)
     return ps.depth > rp.max_depth;
 }
 

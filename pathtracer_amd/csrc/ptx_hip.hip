@@ -122,11 +122,11 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
 #ifdef PTX_PHASE_TIMERS
     WalkCount wc_dbg = {};
     __shared__ unsigned long long ph_lds_[3 * PTX_N_PHASES];
-    if (lane < 3 * PTX_N_PHASES) ph_lds_[lane] = 0ULL;
+    const long long t_begin_dbg = clock64();
+    if (lane < 3 * PTX_N_PHASES) ph_lds_[lane] = lane == PH_LAST ? (unsigned long long)t_begin_dbg : 0ULL;
     __syncthreads();
     wc_dbg.ph = USE_BVH ? nullptr : ph_lds_;
     long long iters_dbg = 0;
-    const long long t_begin_dbg = clock64();
 #endif
     if (PINHOLE && inside) {
         primary_ray(sc, rp, ls, i, j, ks, ps);
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, (TraceShape<USE_BVH, PINHOLE>::wave
             ph_lds_[3 * PH_LOOP + 1] = (unsigned long long)iters_dbg;
         }
         __syncthreads();
-        if (lane < 3 * PTX_N_PHASES && ph_lds_[lane]) atomicAdd(&stats[PTX_STATS_DBG + lane], ph_lds_[lane]);
+        if (lane < 3 * PTX_N_PHASES && lane != PH_LAST && ph_lds_[lane]) atomicAdd(&stats[PTX_STATS_DBG + lane], ph_lds_[lane]);
     }
     {
         // per-lane maxima are what the wave paid: the slowest lane's cycle counts cover the whole loops
@@ -540,6 +540,10 @@ extern "C" int ptx_scene_upload(ptx_context *c, const ptx_scene_desc *s) {
                 g.c[0] = T[3]; g.c[1] = T[7]; g.c[2] = T[11];
                 g.e[0] = T[0] * T[0];
                 g.e[1] = 1.0 / T[0];
+#ifdef PTX_CULL32_PROBE  // (measurement build: single-precision copies in the transform words, which such a sphere does not use)
+                float c32[4] = {(float)g.c[0], (float)g.c[1], (float)g.c[2], (float)g.e[0]};
+                memcpy(&g.m[0], c32, sizeof(c32));
+#endif
             }
             if (o.type == PTX_PLANE) {
                 // normalTransform (reference utils_path.c:58-76) of the two canonical normals, term by term

@@ -10,7 +10,7 @@ pids=()
 while [ $# -ge 2 ]; do
   N=$1; F=$2; shift 2
   ( /opt/rocm/bin/hipcc $BASE $F -c $P/csrc/ptx_hip.hip -o $P/build/var/$N.o 2> $P/build/var/$N.log \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build/var/$N.o $P/build/ptx_bvh.o $P/build/ptx_tonemap.o -o $P/lib/libptx_hip_$N.so \
+    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build/var/$N.o $P/build/ptx_wide.o $P/build/ptx_bvh.o $P/build/ptx_tonemap.o -o $P/lib/libptx_hip_$N.so \
     && echo "built $N" || echo "FAILED $N (see build/var/$N.log)" ) &
   pids+=($!)
 done

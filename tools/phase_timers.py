@@ -33,7 +33,7 @@ if name == "cornell":
     buf = (ctypes.c_ulonglong * N_DBG)()
     assert device._LIB.ptx_debug_counters(dev.ctx, buf, 1) == 0
     v = list(buf)
-    labels = ["closest-hit query", "surface (hit record, material, roulette)", "diffuse direction", "light sample", "shadow query",
+    labels = ["closest-hit query", "surface (hit record, material, roulette)", "diffuse direction + end of the bounce", "light sample", "shadow query",
               "shadow result", "mirror", "refraction", "new path", "glossy deviates", "end of sample (store)", "whole loop"]
     total, iters = v[3 * 11], v[3 * 11 + 1]
     print(f"{name} {size}^2 {spp} spp: wave cycles total {total:.3e}, loop iterations {iters}, {total / iters:.0f} cycles per iteration, paths {st['paths']}")
