@@ -1090,22 +1090,25 @@ __device__ inline void rindex_store(Path &ps, const LaneStore &ls, int k, int ob
     }
 }
 
-// reflectRay, reference PathTracer.c:53-72
+// reflectRay, reference PathTracer.c:53-72, for a unit direction and a unit normal.  The reference normalises both on
+// the way in and the result on the way out; the callers' d has been normalised at the top of the bounce and their
+// normals come normalised from finish_hit, the mirror image of a unit vector in a unit normal is a unit vector, and the
+// next bounce begins by normalising its direction (PathTracer.c:279) -- so the three normalisations would each
+// multiply by one to within rounding, and are left out (a third of the instructions of a mirror bounce).
 __device__ __forceinline__ V3 reflect_dir(V3 d, V3 n) {
-    d = norm3(d);
     double dn = dot3(d, n);
-    return norm3(mk(d.x - 2 * dn * n.x, d.y - 2 * dn * n.y, d.z - 2 * dn * n.z));
+    return mk(d.x - 2 * dn * n.x, d.y - 2 * dn * n.y, d.z - 2 * dn * n.z);
 }
 
-// refractRay, reference PathTracer.c:74-140.  n is normalised in place like
-// the reference's *normal.
+// refractRay, reference PathTracer.c:74-140.  The reference normalises the direction and the normal on the way in and
+// the new direction on the way out; here the direction has been normalised at the top of the bounce, the normal comes
+// normalised from finish_hit, the refracted direction r d + (r c - sqrt(1 - r^2 (1 - c^2))) n of unit d and n is a unit
+// vector, and the next bounce normalises its direction first thing: those normalisations are left out (see reflect_dir).
 __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore &ls, V3 p, V3 &n, int obj, double obj_r_index,
                                    Counters &cnt) {
     double n1 = rindex_load(sc, ps, ls, ps.ridx, cnt.oob);
     double n2 = obj_r_index;
     bool leaving = false;
-    ps.d = norm3(ps.d);
-    n = norm3(n);
     V3 rn = n;
     if (!(dot3(ps.d, n) < 0)) {
         n1 = obj_r_index;
@@ -1125,7 +1128,7 @@ __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore
     double dice = ps.rng.next();
     ps.p0 = p;
     if (disc < 0 || dice <= reflectance) {
-        ps.d = reflect_dir(ps.d, norm3(rn));
+        ps.d = reflect_dir(ps.d, rn);
         return;
     }
     if (leaving) {
@@ -1134,7 +1137,8 @@ __device__ inline void refract_ray(const DevScene &sc, Path &ps, const LaneStore
         ps.ridx = ps.ridx + 1;
         rindex_store(ps, ls, ps.ridx, obj, obj_r_index, cnt.oob);
     }
-    ps.d = norm3(ps.d * r + rn * (r * c - fast_sqrt(disc)));
+    ps.d = ps.d * r + rn * (r * c - fast_sqrt(disc));
+
 }
 
 // Everything of a new path except its ray: initRay (reference utils_path.h:211-230) and PathTrace's initial
@@ -1281,7 +1285,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         V3 dir;
         double scale;
         if (FLAGS & PTX_USE_IS) {
-            dir = norm3(cos_weighted_sample(n, ps.rng));
+            dir = cos_weighted_sample(n, ps.rng);  // a unit vector (rotation of (x, y, sqrt(1 - x^2 - y^2))); normalised at the next bounce's top
             scale = inv_keep;  // (n.dir) / probability with probability = n.dir, reference PathTracer.c:364, :390
         } else {
             dir = uniform_hemisphere_sample(n, ps.rng);
@@ -1331,7 +1335,6 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
         ph_t = PH_T();  // (a branch of its own: the lanes in it have waited for the diffuse branch)
         if (clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        n = norm3(n);
         ps.d = reflect_dir(ps.d, n);
         ps.p0 = p;
         const double sig = mt.refl_sig;
@@ -1436,7 +1439,6 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
     if (is_mirror) {
         if (rp.clean) ps.cel = 0;
         ps.col = mk(ps.col.x * (R * inv_keep), ps.col.y * (G * inv_keep), ps.col.z * (B * inv_keep));
-        n = norm3(n);
         ps.d = reflect_dir(ps.d, n);
         ps.p0 = p;
         const double sig = mt.refl_sig;
@@ -1457,7 +1459,7 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
         V3 dir;
         double scale;
         if (FLAGS & PTX_USE_IS) {
-            dir = norm3(cos_weighted_sample(n, ps.rng));
+            dir = cos_weighted_sample(n, ps.rng);  // a unit vector (rotation of (x, y, sqrt(1 - x^2 - y^2))); normalised at the next bounce's top
             scale = inv_keep;
         } else {
             dir = uniform_hemisphere_sample(n, ps.rng);

@@ -890,7 +890,8 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
     // multiple of four records
     const int round_max = (int)std::min<size_t>(((size_t)nk + 3) & ~(size_t)3, (buf_bytes / bytes_per_pass) & ~(size_t)3);
     if (round_max < 4) return fail(PTX_EINVAL, "sample buffer too small for four passes of this image");
-    const bool pinhole = c->rp.aperture == 0 && !c->rp.clean;  // every sample of a pixel starts along the same direction
+    bool pinhole = c->rp.aperture == 0 && !c->rp.clean;  // every sample of a pixel starts along the same direction
+    if (getenv("PTX_NO_PINHOLE")) pinhole = false;          // (the general variant on a zero aperture: for comparisons)
     const long slots = (long)c->n_cus * 4 * (c->use_bvh ? PTX_BVH_WAVES : (!pinhole ? 3 : 4));  // waves the GPU holds at once
     // Scenes with a hierarchy: the kernel that carries queries in slices (PTX_BVH_KERNEL=whole selects the kernel
     // that runs whole queries, for comparisons; the images are the same).  Its settings were swept at 2048 x 2048 on

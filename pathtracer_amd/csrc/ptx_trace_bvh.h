@@ -80,8 +80,12 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     bool exhausted = false;  // the counter has run past the last work tile
 
     enum { M_NONE = 0, M_CLOSEST = 1, M_SHADOW = 2 };
+    // Paths and queries are counted per wave, from ballots taken where every lane of the wave is present: the counts
+    // are then the same in every lane and live in scalar registers (four counters per lane would cost four vector
+    // registers of a kernel that has none to spare).  Only the out-of-range refraction-stack accesses, counted deep
+    // inside refract_ray, are kept per lane.
     Counters cnt = {0, 0, 0};
-    uint32_t paths = 0;
+    uint32_t w_paths = 0, w_closest = 0, w_shadow = 0;
     Path ps;
     V3 shadow_d = mk(0, 0, 0);  // direction of the lane's shadow query
     double shadow_cb = 0;       // the one field of its ShadowPending besides the direction that stays in registers
@@ -164,6 +168,7 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
         const bool dbg_regen = ended || (mode == M_NONE && k < ke);
 #endif
         DBG_BEGIN();
+        w_paths += (uint32_t)__popcll(__ballot(ended));
         if (ended) {
             // four samples make a 128-byte line of the lane's stream, written once and whole (see k_trace_samples)
             const int slot = (k - ks) & 3;
@@ -185,7 +190,6 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
             mode = M_NONE;
             fresh = false;
             k++;
-            paths++;
         }
         // ---- a new pixel for the lanes that have done theirs
         for (;;) {
@@ -229,8 +233,10 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
                 ke = ks + sub_len < k1 ? ks + sub_len : k1;
                 k = ks;
                 if (PINHOLE) {
-                    primary_ray(sc, rp, ls, i, j, ks, ps);
-                    ls.put(LS_PRIMARY_D + 0, ps.d.x); ls.put(LS_PRIMARY_D + 1, ps.d.y); ls.put(LS_PRIMARY_D + 2, ps.d.z);
+                    // (into a path state of its own: the lane's `ps` is left alone until its next sample starts)
+                    Path first;
+                    primary_ray(sc, rp, ls, i, j, ks, first);
+                    ls.put(LS_PRIMARY_D + 0, first.d.x); ls.put(LS_PRIMARY_D + 1, first.d.y); ls.put(LS_PRIMARY_D + 2, first.d.z);
                 }
             }
             // drop the pixels just handed out: the lowest min(n_need, n_free) set bits
@@ -262,14 +268,14 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
 #ifdef PTX_PHASE_TIMERS
         const bool dbg_fresh = fresh;
 #endif
+        w_closest += (uint32_t)__popcll(__ballot(fresh && mode == M_CLOSEST));
+        w_shadow += (uint32_t)__popcll(__ballot(fresh && mode != M_CLOSEST));
         if (fresh) {
             V3 qd;
             if (mode == M_CLOSEST) {
                 ps.d = norm3(ps.d);
-                cnt.closest++;
                 qd = ps.d;
             } else {
-                cnt.shadow++;
                 qd = shadow_d;
             }
             if (WIDE) query_begin_wide(sc, ps.p0, qd, ps.os, q, wstack);
@@ -323,17 +329,12 @@ __global__ void __launch_bounds__(PTX_BLOCK, PTX_BVH_WAVES)
     }
 #endif
     // one set of atomics per wave
-    unsigned long long c0 = paths, c1 = cnt.closest, c2 = cnt.shadow, c3 = cnt.oob;
-    for (int off = 32; off > 0; off >>= 1) {
-        c0 += __shfl_down(c0, off);
-        c1 += __shfl_down(c1, off);
-        c2 += __shfl_down(c2, off);
-        c3 += __shfl_down(c3, off);
-    }
+    unsigned long long c3 = cnt.oob;
+    for (int off = 32; off > 0; off >>= 1) c3 += __shfl_down(c3, off);
     if (lane == 0) {
-        atomicAdd(&stats[0], c0);
-        atomicAdd(&stats[1], c1);
-        atomicAdd(&stats[2], c2);
+        atomicAdd(&stats[0], (unsigned long long)w_paths);
+        atomicAdd(&stats[1], (unsigned long long)w_closest);
+        atomicAdd(&stats[2], (unsigned long long)w_shadow);
         if (c3) atomicAdd(&stats[3], c3);
     }
 }

@@ -185,20 +185,28 @@ def test_path_radiance_against_reference_vectors_mixed_switches(name, flags, gpu
 
 
 @pytest.mark.parametrize("name,flags,sx,spp,ap", [("cornell", ALL, 64, 8, 0.0), ("cornell", 0, 64, 8, 0.0),
-                                                  ("cornell", ALL, 50, 5, 0.3), ("prims", ALL, 48, 6, 0.1)])
+                                                  ("cornell", ALL, 50, 5, 0.3), ("prims", ALL, 48, 6, 0.1),
+                                                  # the hierarchy kernels, zero aperture (their variant that keeps the primary
+                                                  # direction) and lens, with explicit sampling and without
+                                                  ("bubbletea", ALL, 52, 6, 0.0), ("bubbletea", 3, 52, 4, 0.0), ("bubbletea", ALL, 44, 4, 0.15),
+                                                  ("scifi", ALL, 52, 6, 0.0), ("scifi", 5, 52, 4, 0.0)])
 def test_render_against_oracle_per_pixel(name, flags, sx, spp, ap, gpu, oracles):
-    depth = 6 if name == "cornell" else 8
+    depth = 6 if name == "cornell" else (12 if name in ("bubbletea", "scifi") else 8)
     prm = pt.make_params(sx, depth, flags, ap, seed=2)
     dev = gpu[name]
     dev.render_begin(prm)
     dev.render_passes(0, spp)
     rgb, w = dev.download()
     want, want_w, st = oracles[name].render(prm, 0, spp)
-    keep = ~diagonal_mask(sx) if ap == 0.0 else np.ones(sx * sx, bool)
-    diff = np.abs(rgb.reshape(-1, 3) - want.reshape(-1, 3)).max(axis=1)
-    tol = 1e-9 + 1e-7 * np.abs(want.reshape(-1, 3)).max(axis=1)
+    keep = ~diagonal_mask(sx) if ap == 0.0 and name in ("cornell", "prims") else np.ones(sx * sx, bool)
+    with np.errstate(invalid="ignore"):
+        diff = np.abs(rgb.reshape(-1, 3) - want.reshape(-1, 3)).max(axis=1)
+        tol = 1e-9 + 1e-7 * np.abs(want.reshape(-1, 3)).max(axis=1)
+        # (a pixel that is NaN on both sides -- BubbleTea's negative weights, see the properties test below -- agrees)
+        both_nan = np.isnan(rgb.reshape(-1, 3)).any(axis=1) & np.isnan(want.reshape(-1, 3)).any(axis=1)
+        wrong = ~(diff <= tol) & ~both_nan
     # a pixel is wrong if any of its spp paths flipped; allow spp times the per-path share
-    frac = float((diff[keep] > tol[keep]).mean())
+    frac = float(wrong[keep].mean())
     record(f"pixels/{name} {sx}x{sx} {spp} spp flags {flags} aperture {ap}, against the oracle", pixels=int(keep.sum()),
            pixel_mismatch_fraction=frac, per_path=frac / spp, allowed_per_path=allowed_mismatch(name))
     assert frac <= allowed_mismatch(name) * spp
