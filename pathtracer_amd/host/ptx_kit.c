@@ -333,10 +333,13 @@ void loadTexture(struct object3D *o, const char *filename, int type, struct text
 
 /* ---------------------------------------------------------------- meshes */
 
-/* loadObj (meshes.c:23-101): reads "v x y z" and "f a b c" lines (1-based indices, lines up to 127
- * characters); every face becomes one triangle object with its vertices pre-multiplied by T and the given
- * material.  The reference reads the file in four consecutive sweeps (v, vt, vn, f) without rewinding between
- * them, which is reproduced by the running line cursor. */
+/* loadObj (meshes.c:23-101): reads "v x y z" and "f a b c" lines (1-based indices); every face becomes one
+ * triangle object with its vertices pre-multiplied by T and the given material.  The reference reads the file in
+ * four consecutive sweeps (v, vt, vn, f) without rewinding between them, which is reproduced by the running line
+ * cursor.  Beyond what the reference reads: a line may be of any length (the reference's 128-byte buffer cuts a
+ * longer one into pieces and reads each piece as a line of its own), a face may name its vertices as a/t/n, and
+ * a negative index counts back from the last vertex, as the OBJ format defines it (the reference reads out of
+ * bounds on one). */
 void loadObj(const char *fname, double diff, double refl, double tran, double r, double g, double b, double refl_sig,
              double r_index, struct object3D **list, double T[4][4]) {
     FILE *f = fopen(fname, "r");
@@ -344,13 +347,17 @@ void loadObj(const char *fname, double diff, double refl, double tran, double r,
         fprintf(stderr, "Unable to open mesh file %s\n", fname);
         return;
     }
-    char buf[128];
+    /* every line is kept as its first 127 characters: all a "v" line or the three indices of an "f" line need */
     size_t n_lines = 0, cap = 1024;
     char(*lines)[128] = malloc(cap * 128);
-    while (fgets(buf, 128, f)) {
+    char *whole = NULL;
+    size_t whole_cap = 0;
+    while (getline(&whole, &whole_cap, f) >= 0) {
         if (n_lines == cap) { cap *= 2; lines = realloc(lines, cap * 128); }
-        memcpy(lines[n_lines++], buf, 128);
+        strncpy(lines[n_lines], whole, 127);
+        lines[n_lines++][127] = 0;
     }
+    free(whole);
     fclose(f);
     int vcount = 0, vtcount = 0, vncount = 0, fcount = 0;
     for (size_t k = 0; k < n_lines; k++) {
@@ -392,7 +399,7 @@ void loadObj(const char *fname, double diff, double refl, double tran, double r,
         }
         struct point3D p[3];
         for (int q = 0; q < 3; q++) {
-            int idx = vi[q] - 1;
+            int idx = vi[q] < 0 ? vcount + vi[q] : vi[q] - 1; /* -1 is the last vertex */
             if (idx < 0 || idx >= vcount) idx = 0; /* the reference reads out of bounds here */
             p[q] = vs[idx];
             matVecMult(T, &p[q]);

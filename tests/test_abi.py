@@ -80,5 +80,7 @@ def test_benchmark_kernel_stays_within_its_register_budget():
     if not os.path.exists(obj):
         pytest.skip("object file not built here")
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "kernel_regs.py"), "--check", obj], capture_output=True, text=True)
+    if r.returncode == 3:
+        pytest.skip("the code object could not be read with the tools at hand: " + r.stderr.strip()[-200:])
     assert r.returncode == 0, r.stderr
 

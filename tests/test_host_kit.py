@@ -142,18 +142,25 @@ def test_load_obj_reads_plain_and_slashed_faces(tmp_path):
     extra = "vt 0 0\nvt 1 0\nvn 0 0 1\n"
     plain.write_text(head + extra + "".join(f"f {a} {b} {c}\n" for a, b, c in faces))
     slashed.write_text(head + extra + "".join(f"f {a}/1/1 {b}/2/1 {c}//1\n" for a, b, c in faces))
+    # beyond the reference: a comment of 500 characters (its 128-byte line buffer would read the tail as lines of their
+    # own: one piece here begins with "v " and would become a sixth vertex), and indices counted from the last vertex
+    relative = tmp_path / "relative.obj"
+    long_comment = "# " + "x" * 123 + "v 9 9 9 " + "y" * 360 + "\n"
+    n = len(verts)
+    relative.write_text(long_comment + head + extra + "".join(f"f {a - n - 1} {b - n - 1}/1 {c}\n" for a, b, c in faces))
     lib = C.CDLL(HOST_LIB)
     lib.ptxh_obj_scene_file.argtypes = [C.c_char_p, C.c_char_p]
     scenes = []
-    for src in (plain, slashed):
+    for src in (plain, slashed, relative):
         out = str(tmp_path / (src.stem + ".ptxscene"))
         code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); lib.ptxh_obj_scene_file.argtypes=[ctypes.c_char_p,ctypes.c_char_p];"
                 "sys.exit(0 if lib.ptxh_obj_scene_file(sys.argv[2].encode(), sys.argv[3].encode())==0 else 1)")
         subprocess.run(["python3", "-c", code, HOST_LIB, str(src), out], check=True, capture_output=True)
         scenes.append(Scene.from_file(out))
-    a, b = scenes
-    assert len(a.objects) == 1 + len(faces) == len(b.objects)
+    a, b, c = scenes
+    assert len(a.objects) == 1 + len(faces) == len(b.objects) == len(c.objects)
     assert np.array_equal(a.objects["v"], b.objects["v"]) and np.array_equal(a.objects["box"], b.objects["box"])
+    assert np.array_equal(a.objects["v"], c.objects["v"]) and np.array_equal(a.objects["box"], c.objects["box"])
     tris = a.objects[a.objects["type"] == abi.TRIANGLE]
     by_id = {int(t["src_id"]): t for t in tris}
     for k, f in enumerate(faces):
