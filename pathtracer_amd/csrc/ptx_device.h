@@ -683,14 +683,19 @@ __device__ __forceinline__ long long ph_clock() {
 #define PH_T() 0LL
 #define PH_ADD(wc, i, t0) ((void)0)
 #endif
-template <bool USE_BVH, bool COUNT = false>
+// UNIT: d is a unit vector to within rounding (every ray of the render kernels: a bounce starts by normalising its
+// direction, a shadow ray's direction is a difference times the reciprocal of its length).  The world-space sphere
+// test then takes d.d = 1 instead of computing it, dividing by it and scaling its tolerance with it -- the same
+// lambda to within two units in the last place, for a dot product, a reciprocal and two multiplications per sphere
+// less.  Rays handed in from outside (ptx_first_hit) may have any length: UNIT = false.
+template <bool USE_BVH, bool COUNT = false, bool UNIT = false>
 __device__ __forceinline__ Hit closest_hit_all(const DevScene &sc, V3 p0, V3 d, int os, WalkCount *wc = nullptr) {
     Hit h;
     h.lambda = INFINITY;
     h.obj = -1;
     h.part = 0;
-    const double dd = dot3(d, d);
-    const double inv_dd = fast_rcp(dd);
+    const double dd = UNIT ? 1.0 : dot3(d, d);
+    const double inv_dd = UNIT ? 1.0 : fast_rcp(dd);
     const ConstGeomPtr list_geom = (ConstGeomPtr)sc.list_geom;
     const PTX_CONSTANT_AS int32_t *list_ids = (const PTX_CONSTANT_AS int32_t *)sc.list_ids;
 #ifdef PTX_PHASE_TIMERS
@@ -1245,7 +1250,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
     long long ph_t = PH_T();
     ps.d = norm3(ps.d);
     cnt.closest++;
-    Hit h = closest_hit_all<USE_BVH, COUNT>(sc, ps.p0, ps.d, ps.os, wc);
+    Hit h = closest_hit_all<USE_BVH, COUNT, true>(sc, ps.p0, ps.d, ps.os, wc);
     PH_ADD(wc, PH_QUERY, ph_t);
     if (h.obj < 0) return true;
     const DevMat &mt = sc.mat[h.obj];
@@ -1306,10 +1311,11 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
             V3 lp = light_sample(sc.lights[li], ps.rng);
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
-            V3 ed = dl * fast_rsqrt(d2);
+            const double inv_len = fast_rsqrt(d2);
+            V3 ed = dl * inv_len;
             cnt.shadow++;
             PH_ADD(wc, PH_LIGHT, ph_t);
-                Hit sh = closest_hit_all<USE_BVH, COUNT>(sc, p, ed, h.obj, wc);
+                Hit sh = closest_hit_all<USE_BVH, COUNT, true>(sc, p, ed, h.obj, wc);
             PH_ADD(wc, PH_SHADOW_QUERY, ph_t);
                 int lit = 0;
             if (sh.obj >= 0) {
@@ -1319,7 +1325,7 @@ __device__ inline bool bounce(const DevScene &sc, const DevRender &rp, const Lan
                     double la, lb;
                     finish_hit<false>(sc, sh, p, ed, lpnt, ln, la, lb);
                     double weight2 = dot3(n, ed) * -dot3(ln, ed);
-                    double wgt = (lm.surfaceArea * weight2) * fast_rcp(d2);
+                    double wgt = (lm.surfaceArea * weight2) * (inv_len * inv_len);  // 1 / d2
                     wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
                     if (clean && wgt < 0) wgt = 0;
                     wgt *= inv_keep;
@@ -1479,9 +1485,10 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
             V3 lp = light_sample(sc.lights[li], ps.rng);
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
-            pend.ed = dl * fast_rsqrt(d2);
+            const double inv_len = fast_rsqrt(d2);
+            pend.ed = dl * inv_len;
             ls.put(ls.pend + 0, dot3(n, pend.ed));
-            ls.put(ls.pend + 1, fast_rcp(d2));
+            ls.put(ls.pend + 1, inv_len * inv_len);  // 1 / d2
             ls.put(ls.pend + 2, inv_keep);
             ls.put(ls.pend + 3, ps.col.x * R);
             ls.put(ls.pend + 4, ps.col.y * G);
@@ -1570,8 +1577,7 @@ __device__ __forceinline__ void query_begin(const DevScene &sc, V3 p0, V3 d, int
     q.h.lambda = INFINITY;
     q.h.obj = -1;
     q.h.part = 0;
-    const double dd = dot3(d, d);
-    const double inv_dd = fast_rcp(dd);
+    const double dd = 1.0, inv_dd = 1.0;  // d is a unit vector (see closest_hit_all, UNIT)
     list_hits_nb(sc, p0, d, os, dd, inv_dd, q.h);
     q.best = __double2float_ru(q.h.lambda);
     q.ix = rcp_for_slab32(d.x);
@@ -1621,9 +1627,8 @@ __device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q,
 }
 __device__ __forceinline__ void query_leaf(const DevScene &sc, V3 p0, V3 d, Query &q) {
     const int leaf = q.leaf, id = leaf & PTX_LEAF_INDEX;
-    const double dd = dot3(d, d);
     int part;
-    double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, dd, fast_rcp(dd), part);
+    double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, 1.0, 1.0, part);  // (unit d)
     if (lam > PT_TOL && (lam < q.h.lambda || (lam == q.h.lambda && id < q.h.obj))) {
         q.h.lambda = lam;
         q.h.obj = id;
@@ -1666,8 +1671,7 @@ __device__ __forceinline__ void query_begin_wide(const DevScene &sc, V3 p0, V3 d
     q.h.lambda = INFINITY;
     q.h.obj = -1;
     q.h.part = 0;
-    const double dd = dot3(d, d);
-    const double inv_dd = fast_rcp(dd);
+    const double dd = 1.0, inv_dd = 1.0;  // d is a unit vector (see closest_hit_all, UNIT)
     list_hits_nb(sc, p0, d, os, dd, inv_dd, q.h);
     q.best = __double2float_ru(q.h.lambda);
     q.ix = rcp_for_slab32(d.x);
