@@ -57,7 +57,7 @@ def main():
     # visit there is one 128-byte node and four box tests.  The path kernel that counts visits walks the binary form, so
     # the wide visits per ray come from the instrumented render kernel (tools/phase_timers.py: "node visits per query"),
     # given as PTX_WIDE_VISITS_PER_RAY.
-    wide_visits = float(os.environ["PTX_WIDE_VISITS_PER_RAY"]) if "PTX_WIDE_VISITS_PER_RAY" in os.environ else None
+    wide_visits = float(os.environ["PTX_WIDE_VISITS_PER_RAY"]) if os.environ.get("PTX_WIDE_VISITS_PER_RAY") else None
     if wide_visits is not None:
         flop = 4 * 24 * wide_visits + sum(c * (a + b) for c, a, b in zip(PRIM_FLOP, leaf, list_by_type)) + 40 * hits
         byts = 128 * wide_visits + 160 * sum(leaf) + 48 * texels
