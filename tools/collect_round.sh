@@ -19,3 +19,8 @@ for s in scifi bubbletea meshstress; do
 done
 timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+timeout -k 10 300 python3 tools/build_time.py 1,8 > $OUT/build_time.txt 2>&1
+cat $OUT/build_time.txt
+for s in scifi bubbletea meshstress; do
+  timeout -k 10 300 python3 tools/phase_timers.py $s 2048 25 > $OUT/${s}_phases.txt 2>&1
+done
