@@ -866,6 +866,80 @@ __device__ __forceinline__ void finish_hit(const DevScene &sc, const Hit &h, V3 
     n = xform_normal(m, nc);
 }
 
+// The same with the head of the primitive's record fetched beforehand.  finish_hit asks for the record piece by piece as
+// its branches are reached: the type first, then what that type needs -- two or three requests one after the other, each
+// a trip to the cache that the lane waits for.  The kernels for scenes with a hierarchy wait for memory more than for
+// anything else, so shade_hit and apply_shadow request, in one go and together with the material record, everything
+// that settles the common hits (triangles, uniformly scaled spheres, planes without texture coordinates); only the
+// general case fetches the rest of the transform afterwards.  Same operations on the same values as finish_hit.
+struct GeomHead {
+    int type, fast;
+    double m8, m9, m10, m11;  // the last row of Tinv; a triangle's unit normal in m9..m11
+    double c[3], e[3];
+};
+// Keeps a value that has been requested from memory from being requested later instead: the compiler moves a load that
+// has a single use into the branch that uses it, which is where the wait for it would then be.
+template <typename T>
+__device__ __forceinline__ void keep_here(T &v) {
+    asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ GeomHead geom_head(const DevGeom &g) {
+    GeomHead gh;
+    gh.type = g.type;
+    gh.fast = g.fast;
+    gh.m8 = g.m[8];
+    gh.m9 = g.m[9];
+    gh.m10 = g.m[10];
+    gh.m11 = g.m[11];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        gh.c[q] = g.c[q];
+        gh.e[q] = g.e[q];
+    }
+    return gh;
+}
+__device__ __forceinline__ void keep_here(GeomHead &gh) {
+    keep_here(gh.type);
+    keep_here(gh.fast);
+    keep_here(gh.m8);
+    keep_here(gh.m9);
+    keep_here(gh.m10);
+    keep_here(gh.m11);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        keep_here(gh.c[q]);
+        keep_here(gh.e[q]);
+    }
+}
+template <bool WANT_UV>
+__device__ __forceinline__ void finish_hit_pre(const DevScene &sc, const Hit &h, const GeomHead &gh, V3 p0, V3 d, V3 &p, V3 &n,
+                                               double &a, double &b) {
+    const int type = gh.type;
+    p = p0 + d * h.lambda;
+    a = 0;
+    b = 0;
+    if (type == PTX_TRIANGLE) {
+        V3 nn = mk(gh.m9, gh.m10, gh.m11);
+        n = h.part ? nn * -1.0 : nn;
+        return;
+    }
+    if (gh.fast) {
+        V3 pc = mk(p.x - gh.c[0], p.y - gh.c[1], p.z - gh.c[2]) * gh.e[1];
+        n = norm3(pc);
+        if (WANT_UV) {
+            a = atan2(pc.y, pc.x) / (2 * PT_PI);
+            b = acos(pc.z) / PT_PI;
+        }
+        return;
+    }
+    if (!WANT_UV && type == PTX_PLANE) {
+        double tz = gh.m8 * p0.x + gh.m9 * p0.y + gh.m10 * p0.z + gh.m11;
+        n = tz < 0 ? mk(gh.e[0], gh.e[1], gh.e[2]) : mk(gh.c[0], gh.c[1], gh.c[2]);
+        return;
+    }
+    finish_hit<WANT_UV>(sc, h, p0, d, p, n, a, b);  // the general case, with the whole record
+}
+
 // ------------------------------------------------------ texture look-ups
 // byte / divisor, rounded as the IEEE division the reference performs when it loads an image
 // (utils_path.c:1849, :1921): quotient from the reciprocal (inv = fast_rcp(divisor)), then one correction with
@@ -1411,15 +1485,22 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
     over = false;
     if (h.obj < 0) return SH_END;
     const DevMat &mt = sc.mat[h.obj];
-    const int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img;
+    // the material and the head of the primitive's record in one request (see finish_hit_pre)
+    GeomHead gh = geom_head(sc.geom[h.obj]);
+    int tex_img = mt.tex_img, normal_img = mt.normal_img, alpha_img = mt.alpha_img, is_light = mt.is_light;
+    double R = mt.col[0], G = mt.col[1], B = mt.col[2];
+    double mt_diff = mt.diffPct, mt_refl = mt.reflPct, mt_tran = mt.tranPct;
+    keep_here(gh);
+    keep_here(tex_img); keep_here(normal_img); keep_here(alpha_img); keep_here(is_light);
+    keep_here(R); keep_here(G); keep_here(B);
+    keep_here(mt_diff); keep_here(mt_refl); keep_here(mt_tran);
     V3 p, n;
     double a, b;
-    if ((tex_img & normal_img & alpha_img) >= 0) finish_hit<true>(sc, h, ps.p0, ps.d, p, n, a, b);  // any index >= 0
-    else finish_hit<false>(sc, h, ps.p0, ps.d, p, n, a, b);
-    double R = mt.col[0], G = mt.col[1], B = mt.col[2];
+    if ((tex_img & normal_img & alpha_img) >= 0) finish_hit_pre<true>(sc, h, gh, ps.p0, ps.d, p, n, a, b);  // any index >= 0
+    else finish_hit_pre<false>(sc, h, gh, ps.p0, ps.d, p, n, a, b);
     if (tex_img >= 0) tex_map<true>(sc, tex_img, a, b, R, G, B);
     if (normal_img >= 0) n = normal_deform<true>(sc, normal_img, a, b, n);
-    if (mt.is_light) {
+    if (is_light) {
         if (!ps.cel) ps.I = mk(ps.I.x + ps.col.x * R, ps.I.y + ps.col.y * G, ps.I.z + ps.col.z * B);
         return SH_END;
     }
@@ -1431,12 +1512,12 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
         if (rr >= .98) rr = .98;
     }
     if (rr > ps.rng.next()) return SH_END;
-    double diffusivity = mt.diffPct, reflectivity = mt.reflPct, transparency = mt.tranPct;
+    double diffusivity = mt_diff, reflectivity = mt_refl, transparency = mt_tran;
     if (alpha_img >= 0) {
         transparency = alpha_map(sc, alpha_img, a, b);
         double both = reflectivity + diffusivity;
-        reflectivity = (1 - transparency) * mt.reflPct / both;
-        diffusivity = (1 - transparency) * mt.diffPct / both;
+        reflectivity = (1 - transparency) * mt_refl / both;
+        diffusivity = (1 - transparency) * mt_diff / both;
     }
     const double inv_keep = (FLAGS & PTX_USE_RR) ? fast_rcp(1 - rr) : 1.0;
     double dice = ps.rng.next();
@@ -1482,12 +1563,22 @@ __device__ inline int shade_hit(const DevScene &sc, const DevRender &rp, const L
         if (FLAGS & PTX_USE_ES) {
             double u = ps.rng.next();
             int li = 0;
-            double acc = sc.lights[0].weight;
-            while (acc < u && li + 1 < sc.n_lights) {
-                li++;
-                acc += sc.lights[li].weight;
+            if (sc.n_lights > 1) {  // (with a single light the walk below never moves and its weight is not needed)
+                double acc = sc.lights[0].weight;
+                while (acc < u && li + 1 < sc.n_lights) {
+                    li++;
+                    acc += sc.lights[li].weight;
+                }
             }
-            V3 lp = light_sample(sc.lights[li], ps.rng);
+            // the light's record in one request, type and transform together (light_sample asks for the type first)
+            DevLight lt;
+            lt.type = sc.lights[li].type;
+#pragma unroll
+            for (int q = 0; q < 12; q++) lt.T[q] = sc.lights[li].T[q];
+            keep_here(lt.type);
+#pragma unroll
+            for (int q = 0; q < 12; q++) keep_here(lt.T[q]);
+            V3 lp = light_sample(lt, ps.rng);
             V3 dl = lp - p;
             double d2 = dot3(dl, dl);
             const double inv_len = fast_rsqrt(d2);
@@ -1520,16 +1611,24 @@ __device__ inline void apply_shadow(const DevScene &sc, const DevRender &rp, Pat
     int lit = 0;
     if (sh.obj >= 0) {
         const DevMat &lm = sc.mat[sh.obj];
-        if (lm.is_light) {
+        // what a light's contribution needs, all of it requested before the first of it is looked at: one wait instead of
+        // four in a row (the material's flag, the primitive's type, its plane, its normal)
+        GeomHead gh = geom_head(sc.geom[sh.obj]);
+        int is_light = lm.is_light;
+        double area = lm.surfaceArea, lr = lm.col[0], lg = lm.col[1], lb_ = lm.col[2];
+        keep_here(gh);
+        keep_here(is_light);
+        keep_here(area); keep_here(lr); keep_here(lg); keep_here(lb_);
+        if (is_light) {
             V3 lpnt, ln;
             double la, lb;
-            finish_hit<false>(sc, sh, ps.p0, pend.ed, lpnt, ln, la, lb);
+            finish_hit_pre<false>(sc, sh, gh, ps.p0, pend.ed, lpnt, ln, la, lb);
             double weight2 = pend.n_ed * -dot3(ln, pend.ed);
-            double wgt = (lm.surfaceArea * weight2) * pend.rcp_d2;
+            double wgt = (area * weight2) * pend.rcp_d2;
             wgt = 1 > wgt ? wgt : 1;  // min(1, .), reference PathTracer.c:437
             if (rp.clean && wgt < 0) wgt = 0;
             wgt *= pend.inv_keep;
-            ps.I = mk(ps.I.x + pend.cr * lm.col[0] * wgt, ps.I.y + pend.cg * lm.col[1] * wgt, ps.I.z + pend.cb * lm.col[2] * wgt);
+            ps.I = mk(ps.I.x + pend.cr * lr * wgt, ps.I.y + pend.cg * lg * wgt, ps.I.z + pend.cb * lb_ * wgt);
             lit = 1;
         }
     }
@@ -1633,7 +1732,19 @@ __device__ __forceinline__ void query_step(const DevScene &sc, int os, Query &q,
 __device__ __forceinline__ void query_leaf(const DevScene &sc, V3 p0, V3 d, Query &q) {
     const int leaf = q.leaf, id = leaf & PTX_LEAF_INDEX;
     int part;
-    double lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, 1.0, 1.0, part);  // (unit d)
+    double lam;
+    if ((leaf >> PTX_LEAF_TYPE_SHIFT) == PTX_TRIANGLE) {
+        // a triangle's record in one request: the test asks for the normal and a vertex, and for the other two vertices
+        // only behind its early returns, which is a second wait for memory in a phase that does little else
+        double m[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) m[c] = sc.geom[id].m[c];
+#pragma unroll
+        for (int c = 0; c < 12; c++) keep_here(m[c]);
+        lam = isect_triangle(m, p0, d, part);
+    } else {
+        lam = isect_typed(&sc.geom[id], leaf >> PTX_LEAF_TYPE_SHIFT, leaf & PTX_LEAF_FAST, p0, d, 1.0, 1.0, part);  // (unit d)
+    }
     if (lam > PT_TOL && (lam < q.h.lambda || (lam == q.h.lambda && id < q.h.obj))) {
         q.h.lambda = lam;
         q.h.obj = id;
@@ -1698,11 +1809,33 @@ __device__ __forceinline__ void query_begin_wide(const DevScene &sc, V3 p0, V3 d
 // would cost 24 instructions a step).  While every lane of the wave has its whole stack in LDS -- always, but for trees
 // of unusual depth -- popping is one LDS read and pushing one LDS write per child without a branch (a child the ray
 // does not enter is written too and overwritten by the next push).
+#ifdef PTX_WIDE_DIAG
+// Diagnosis only: what the four-wide walk does, summed over a launch (ptx_debug_wide_diag reads and clears).
+static __device__ unsigned long long g_wide_diag[16];
+#define WIDE_DIAG(i, cond)                                                                     \
+    do {                                                                                       \
+        const unsigned long long m_ = __ballot(cond);                                          \
+        if (m_ && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_wide_diag[i], (unsigned long long)__popcll(m_)); \
+    } while (0)
+#else
+#define WIDE_DIAG(i, cond) ((void)0)
+#endif
 __device__ __forceinline__ void query_step_wide(const DevScene &sc, int os, Query &q, const WideStack &st) {
     const int top = --q.node;
     int e;
+    WIDE_DIAG(4, top >= st.lds_n);
+    WIDE_DIAG(8 + (0), top < 4);
+    WIDE_DIAG(8 + (1), top >= 4 && top < 8);
+    WIDE_DIAG(8 + (2), top >= 8 && top < 12);
+    WIDE_DIAG(8 + (3), top >= 12 && top < 16);
+    WIDE_DIAG(8 + (4), top >= 16 && top < 20);
+    WIDE_DIAG(8 + (5), top >= 20 && top < 28);
+    WIDE_DIAG(8 + (6), top >= 28 && top < 40);
+    WIDE_DIAG(8 + (7), top >= 40);
     if (__ballot(top >= st.lds_n) == 0ULL) e = st.lds[top * PTX_BLOCK];
     else e = st.get(top);
+    WIDE_DIAG(5, e >= 0);
+    WIDE_DIAG(6, e >= 0 && (e & PTX_LEAF_INDEX) == os);
     if (e >= 0) {
         q.leaf = (e & PTX_LEAF_INDEX) != os ? e : -1;
         return;
@@ -1728,6 +1861,11 @@ __device__ __forceinline__ void query_step_wide(const DevScene &sc, int os, Quer
     PTX_WIDE_CHILD(w, 3)
 #undef PTX_WIDE_CHILD
     const unsigned order = ((q.base & 4 ? ord.y : ord.x) >> (8 * (q.base & 3))) & 255u;
+    WIDE_DIAG(0, true);
+    WIDE_DIAG(1, hits == 0);
+    WIDE_DIAG(2, hits & 1); WIDE_DIAG(2, hits & 2); WIDE_DIAG(2, hits & 4); WIDE_DIAG(2, hits & 8);
+    WIDE_DIAG(3, q.node + __popc(hits) > st.lds_n);
+    WIDE_DIAG(7, __popc(hits) >= 3);
     if (__ballot(q.node + 4 > st.lds_n) == 0ULL) {
 #pragma unroll
         for (int t = 3; t >= 0; t--) {

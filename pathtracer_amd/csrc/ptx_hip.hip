@@ -922,10 +922,11 @@ static int render_rounds(ptx_context *c, int k0, int nk, double *buf, size_t buf
         burst = nodes_in_l2 ? 6 : 4, small_run = 8;
     // the four-wide walk: a step is four box tests and a stack operation, worth two or three steps of the binary walk, and a
     // lane needs four or five of them for a query; short bursts, and the walk is left early (swept on the mesh of a
-    // million triangles, tools/sweep_walk.py: bursts of 2, 32 lanes, leaves tested sixteen at a time)
+    // million triangles, tools/sweep_walk.py: bursts of 2, 40 lanes, leaves tested eight at a time; flat within 1 %
+    // between 32 and 48 lanes and between 8 and 16 leaves)
     if (c->sc.wide != nullptr) {
-        exit_lanes = 32;
-        leaf_batch = 16;
+        exit_lanes = 40;
+        leaf_batch = 8;
         shade_min = 24;
         burst = 2;
     }

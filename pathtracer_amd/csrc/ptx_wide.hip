@@ -25,3 +25,13 @@ void ptx_launch_trace_bvh_wide(int flags, bool pinhole, dim3 grid, hipStream_t s
     default: launch_wide_flags<7>(pinhole, grid, stream, a); break;
     }
 }
+
+#ifdef PTX_WIDE_DIAG
+extern "C" int ptx_debug_wide_diag(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_diag), sizeof(g_wide_diag)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_diag), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

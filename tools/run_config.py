@@ -11,6 +11,10 @@ import numpy as np
 
 import pathtracer_amd as pt
 
+if os.environ.get("PTX_LIB"):  # an alternative build of the library (a file name under pathtracer_amd/lib), for A/B measurements
+    from pathtracer_amd import device
+    device._LIB = device.load_library(os.path.join(REPO, "pathtracer_amd", "lib", os.environ["PTX_LIB"]))
+
 CONFIGS = {"scifi": (2048, 12, 400, 0.05), "bubbletea": (2048, 12, 2000, 0.15), "meshstress": (2048, 8, 100, 0.0)}
 name = sys.argv[1]
 sx, depth, spp, ap = CONFIGS[name]
