@@ -24,3 +24,6 @@ cat $OUT/build_time.txt
 for s in scifi bubbletea meshstress; do
   timeout -k 10 300 python3 tools/phase_timers.py $s 2048 25 > $OUT/${s}_phases.txt 2>&1
 done
+for s in scifi bubbletea meshstress; do
+  bash tools/collect_config_profiles.sh ${TAG}_$s $s 1024 > gpurun_out/${TAG}_${s}_collect.log 2>&1 || { echo "counters of $s failed"; tail -3 gpurun_out/${TAG}_${s}_collect.log; }
+done
